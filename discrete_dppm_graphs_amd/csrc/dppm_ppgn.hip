@@ -1,0 +1,553 @@
+// PPGN ("Powerful") denoiser forward/backward for gfx950 behind the C-ABI of include/dppm_hip.h.
+//
+// Data layout in HBM: every activation is a stack of channel-first planes [B][C][N][ld] (ld = N rounded up to 4,
+// P = N*ld floats per plane, pad columns hold zeros wherever a tensor is masked).  In this layout
+//   - each nn.Linear of the reference (applied at every (i,j), model/ppgn.py:58-59,69,301,327-333) is a plain
+//     row-major GEMM  Y[b] (O x P) = W (O x I) * X[b] (I x P)  with the weight in torch's own [out][in] layout,
+//   - the per-channel contraction out1 @ out2 (model/ppgn.py:62) reads and writes contiguous N x ld planes,
+//   - the masked instance norm (util/model_helper.py:176-191) reduces over one contiguous plane,
+//   - torch.cat along features (model/ppgn.py:66,318) is adjacency of planes: the skip-concat Linear is a
+//     two-segment K loop and the readout reads the layer outputs where they already lie (buffer CAT).
+// so the reference's permutes and cats never cost a byte.  All GEMMs run on v_mfma_f32_32x32x2_f32 (dppm_gemm.h).
+#include "dppm_gemm.h"
+
+namespace dppm {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------------
+struct Layout {
+  int B, N, H, L, ld, P, CT;       // CT = 2 + L*H channels of CAT
+  size_t S;                        // floats in one [B][H][P] plane set
+  size_t maskp, inv_norm, cat, u0, R, act, tmp[4];
+  size_t hid1, hid2, o1, o2, mm;   // per-layer saves (training): base + l * S
+  size_t rstd;                     // [L][B][H]
+  size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum;
+  size_t slab_floats, total;
+  int training;
+};
+
+constexpr size_t kAlign = 64;   // floats (256 B)
+inline size_t bump(size_t& off, size_t n) {
+  const size_t at = off;
+  off += (n + kAlign - 1) / kAlign * kAlign;
+  return at;
+}
+
+inline int wgrad_nsplit(int B, int P) {   // K chunks per graph so that ~1024 workgroups exist
+  int per = cdiv(1024, B);
+  int kchunk = round_up(cdiv(P, per), 256);
+  if (kchunk < 256) kchunk = 256;
+  return cdiv(P, kchunk);
+}
+inline int wgrad_kchunk(int B, int P) { return round_up(cdiv(P, wgrad_nsplit(B, P)), BK); }
+
+Layout make_layout(int B, int N, int H, int L, int training) {
+  Layout w{};
+  w.B = B; w.N = N; w.H = H; w.L = L; w.training = training;
+  w.ld = round_up(N, 4);
+  w.P = N * w.ld;
+  w.CT = 2 + L * H;
+  w.S = (size_t)B * H * w.P;
+  size_t off = 0;
+  w.maskp = bump(off, (size_t)B * w.P);
+  w.inv_norm = bump(off, B);
+  w.cat = bump(off, (size_t)B * w.CT * w.P);
+  w.u0 = bump(off, w.S);
+  w.R = bump(off, w.S);
+  w.act = bump(off, w.S);
+  w.rstd = bump(off, (size_t)L * B * H);
+  if (!training) {
+    for (int i = 0; i < 4; ++i) w.tmp[i] = bump(off, w.S);
+  } else {
+    w.tmp[3] = bump(off, w.S);   // y
+    w.hid1 = bump(off, w.S * L); w.hid2 = bump(off, w.S * L);
+    w.o1 = bump(off, w.S * L); w.o2 = bump(off, w.S * L); w.mm = bump(off, w.S * L);
+    w.dh = bump(off, w.S); w.dz = bump(off, w.S);
+    w.dcat = bump(off, (size_t)B * w.CT * w.P);
+    w.dy = bump(off, w.S); w.dmm = bump(off, w.S); w.do1 = bump(off, w.S); w.do2 = bump(off, w.S);
+    w.du0 = bump(off, w.S);
+    const int nz = B * wgrad_nsplit(B, w.P);
+    w.slab_floats = (size_t)nz * H * (size_t)(w.CT > 2 * H ? w.CT : 2 * H);
+    w.slabs = bump(off, w.slab_floats);
+    w.rsum = bump(off, (size_t)nz * H + (size_t)B * H + B);
+  }
+  w.total = off;
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------------------
+
+// Input planes: CAT[b][0] = A (padded), CAT[b][1] = sigma_b on the diagonal (model/ppgn.py:283-293), the padded mask
+// and 1/sqrt(#active nodes) from mask row 0 (model/ppgn.py:51).
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ A, const float* __restrict__ mask,
+                                                   const float* __restrict__ sigma, int N, int ld, int CT,
+                                                   float* __restrict__ cat, float* __restrict__ maskp,
+                                                   float* __restrict__ inv_norm) {
+  const int b = blockIdx.y;
+  const int P = N * ld;
+  float* c0 = cat + (size_t)b * CT * P;
+  float* c1 = c0 + P;
+  const float sg = sigma[b];
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int i = p / ld, j = p % ld;
+    const bool in = j < N;
+    const size_t src = ((size_t)b * N + i) * N + j;
+    c0[p] = in ? A[src] : 0.f;
+    c1[p] = (in && i == j) ? sg : 0.f;
+    maskp[(size_t)b * P + p] = in ? mask[src] : 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    float s = 0.f;
+    for (int j = threadIdx.x; j < N; j += 64) s += mask[(size_t)b * N * N + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) inv_norm[b] = 1.f / sqrtf(s);
+  }
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {   // all threads get the total
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int k = 0; k < nw; ++k) t += sh[k];
+  return t;
+}
+
+constexpr int NORM_THREADS = 1024;
+constexpr int NORM_CACHE = 10;   // float4 per thread kept in registers: planes up to 40960 floats stay on chip
+
+// masked instance norm, one workgroup per (b,c) plane: mean, then variance around it, then normalise
+// (two-pass statistics as in util/model_helper.py:182-189; the plane is read from HBM once and kept in registers)
+__global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __restrict__ y, long y_bs,
+                                                                 const float* __restrict__ maskp, float* __restrict__ u,
+                                                                 long u_bs, int C, int P, float* __restrict__ mean_out,
+                                                                 float* __restrict__ rstd_out) {
+  __shared__ float sh[NORM_THREADS / 64];
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const float4* yp = reinterpret_cast<const float4*>(y + (size_t)b * y_bs + (size_t)c * P);
+  const float4* mp = reinterpret_cast<const float4*>(maskp + (size_t)b * P);
+  float4* up = reinterpret_cast<float4*>(u + (size_t)b * u_bs + (size_t)c * P);
+  const int P4 = P / 4;
+  float4 cy[NORM_CACHE], cm[NORM_CACHE];
+  float s = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int v = 0; v < NORM_CACHE; ++v) {
+    const int idx = threadIdx.x + v * NORM_THREADS;
+    cy[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cm[v] = cy[v];
+    if (idx < P4) { cy[v] = yp[idx]; cm[v] = mp[idx]; }
+    s += cy[v].x * cm[v].x + cy[v].y * cm[v].y + cy[v].z * cm[v].z + cy[v].w * cm[v].w;
+    cnt += cm[v].x + cm[v].y + cm[v].z + cm[v].w;
+  }
+  for (int idx = threadIdx.x + NORM_CACHE * NORM_THREADS; idx < P4; idx += NORM_THREADS) {
+    const float4 a = yp[idx], m = mp[idx];
+    s += a.x * m.x + a.y * m.y + a.z * m.z + a.w * m.w;
+    cnt += m.x + m.y + m.z + m.w;
+  }
+  s = block_sum_1024(s, sh);
+  cnt = block_sum_1024(cnt, sh);
+  const float mean = s / cnt;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < NORM_CACHE; ++v) {
+    const float dx = (cy[v].x - mean) * cm[v].x, dy = (cy[v].y - mean) * cm[v].y;
+    const float dz = (cy[v].z - mean) * cm[v].z, dw = (cy[v].w - mean) * cm[v].w;
+    q += dx * dx + dy * dy + dz * dz + dw * dw;
+  }
+  for (int idx = threadIdx.x + NORM_CACHE * NORM_THREADS; idx < P4; idx += NORM_THREADS) {
+    const float4 a = yp[idx], m = mp[idx];
+    const float dx = (a.x - mean) * m.x, dy = (a.y - mean) * m.y, dz = (a.z - mean) * m.z, dw = (a.w - mean) * m.w;
+    q += dx * dx + dy * dy + dz * dz + dw * dw;
+  }
+  q = block_sum_1024(q, sh);
+  const float rstd = 1.f / sqrtf(q / cnt + 1e-5f);
+#pragma unroll
+  for (int v = 0; v < NORM_CACHE; ++v) {
+    const int idx = threadIdx.x + v * NORM_THREADS;
+    if (idx < P4)
+      up[idx] = make_float4((cy[v].x - mean) * rstd * cm[v].x, (cy[v].y - mean) * rstd * cm[v].y,
+                            (cy[v].z - mean) * rstd * cm[v].z, (cy[v].w - mean) * rstd * cm[v].w);
+  }
+  for (int idx = threadIdx.x + NORM_CACHE * NORM_THREADS; idx < P4; idx += NORM_THREADS) {
+    const float4 a = yp[idx], m = mp[idx];
+    up[idx] = make_float4((a.x - mean) * rstd * m.x, (a.y - mean) * rstd * m.y, (a.z - mean) * rstd * m.z,
+                          (a.w - mean) * rstd * m.w);
+  }
+  if (threadIdx.x == 0) {
+    if (mean_out) mean_out[blockIdx.x] = mean;
+    if (rstd_out) rstd_out[blockIdx.x] = rstd;
+  }
+}
+
+// dy = rstd * m * (g - mean_m(g) - u * mean_m(g*u))   (u already carries the mask)
+__global__ __launch_bounds__(NORM_THREADS) void inorm_bwd_kernel(const float* __restrict__ g, long g_bs,
+                                                                 const float* __restrict__ u, long u_bs,
+                                                                 const float* __restrict__ maskp,
+                                                                 const float* __restrict__ rstd_in, float* __restrict__ dy,
+                                                                 int C, int P) {
+  __shared__ float sh[NORM_THREADS / 64];
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const float4* gp = reinterpret_cast<const float4*>(g + (size_t)b * g_bs + (size_t)c * P);
+  const float4* up = reinterpret_cast<const float4*>(u + (size_t)b * u_bs + (size_t)c * P);
+  const float4* mp = reinterpret_cast<const float4*>(maskp + (size_t)b * P);
+  float4* dp = reinterpret_cast<float4*>(dy + ((size_t)b * C + c) * P);
+  const int P4 = P / 4;
+  float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+  for (int idx = threadIdx.x; idx < P4; idx += NORM_THREADS) {
+    const float4 a = gp[idx], x = up[idx], m = mp[idx];
+    s1 += a.x * m.x + a.y * m.y + a.z * m.z + a.w * m.w;
+    s2 += a.x * x.x + a.y * x.y + a.z * x.z + a.w * x.w;
+    cnt += m.x + m.y + m.z + m.w;
+  }
+  s1 = block_sum_1024(s1, sh);
+  s2 = block_sum_1024(s2, sh);
+  cnt = block_sum_1024(cnt, sh);
+  const float rstd = rstd_in[blockIdx.x];
+  const float m1 = s1 / cnt, m2 = s2 / cnt;
+  for (int idx = threadIdx.x; idx < P4; idx += NORM_THREADS) {
+    const float4 a = gp[idx], x = up[idx], m = mp[idx];
+    dp[idx] = make_float4(rstd * m.x * (a.x - m1 - x.x * m2), rstd * m.y * (a.y - m1 - x.y * m2),
+                          rstd * m.z * (a.z - m1 - x.z * m2), rstd * m.w * (a.w - m1 - x.w * m2));
+  }
+}
+
+// logits[b][i][j] = sum_o wfin[o] * (R + act)[b][o][p] + bfin     (model/ppgn.py:331-333; dropout is identity in eval)
+__global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict__ R, const float* __restrict__ act,
+                                                        const float* __restrict__ wfin, const float* __restrict__ bfin,
+                                                        int H, int N, int ld, float* __restrict__ logits) {
+  const int b = blockIdx.y;
+  const int P = N * ld;
+  const float bias = bfin[0];
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int i = p / ld, j = p % ld;
+    if (j >= N) continue;
+    float acc = 0.f;
+    const float* r = R + (size_t)b * H * P + p;
+    const float* a = act + (size_t)b * H * P + p;
+    for (int o = 0; o < H; ++o) acc += wfin[o] * (r[(size_t)o * P] + a[(size_t)o * P]);
+    logits[((size_t)b * N + i) * N + j] = acc + bias;
+  }
+}
+
+// Backward of the head, one workgroup per (b,o) plane:
+//   dh = wfin[o] * dl ; dz = dh * LeakyReLU'(act) ; dwfin partial = sum_p (R+act) * dl ; dbfin partial = sum_p dl
+__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ R, const float* __restrict__ act,
+                                                        const float* __restrict__ wfin, const float* __restrict__ dlogits,
+                                                        int H, int N, int ld, float* __restrict__ dh, float* __restrict__ dz,
+                                                        float* __restrict__ dw_part, float* __restrict__ db_part) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x / H, o = blockIdx.x % H;
+  const int P = N * ld;
+  const size_t base = ((size_t)b * H + o) * P;
+  const float w = wfin[o];
+  float sw = 0.f, sb = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    const int i = p / ld, j = p % ld;
+    const float dl = j < N ? dlogits[((size_t)b * N + i) * N + j] : 0.f;
+    const float a = act[base + p];
+    const float h = R[base + p] + a;
+    const float d = w * dl;
+    dh[base + p] = d;
+    dz[base + p] = d * (a > 0.f ? 1.f : kSlope);
+    sw += h * dl;
+    sb += dl;
+  }
+  sw = block_sum_1024(sw, sh);
+  sb = block_sum_1024(sb, sh);
+  if (threadIdx.x == 0) {
+    dw_part[blockIdx.x] = sw;
+    if (o == 0) db_part[b] = sb;
+  }
+}
+
+// out[m*ldo + n] = sum_z slabs[z][m*N + n]   (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nz, int M, int N,
+                                                           float* __restrict__ out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * N) return;
+  float acc = 0.f;
+  for (int z = 0; z < nz; ++z) acc += slabs[(size_t)z * M * N + e];
+  out[(size_t)(e / N) * ldo + (e % N)] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------------------------------------
+struct Ctx {
+  hipStream_t st;
+  Layout w;
+  float* ws;
+  float* at(size_t off) const { return ws + off; }
+};
+
+GemmArgs base_args() {
+  GemmArgs a{};
+  a.nseg = 1; a.nsplit = 1; a.kchunk = 0; a.scale_div = 1; a.mul_div = 1;
+  return a;
+}
+
+// Y[b] (M x P) = epilogue( sum_s W_s (M x K_s) * X_s[b] (K_s x P) )
+struct LinArgs {
+  const float* W; int ldw; bool w_trans;   // w_trans: use W^T (W is stored [K][M] with pitch ldw)
+  const float* X; long x_bs; int K;
+};
+int linear(const Ctx& c, int M, const LinArgs& s0, const LinArgs* s1, const float* bias, int act, const float* mulmask,
+           const float* dact, long dact_bs, float* Y, long y_bs, bool accumulate) {
+  GemmArgs a = base_args();
+  const LinArgs* segs[2] = {&s0, s1};
+  a.nseg = s1 ? 2 : 1;
+  a.a_vec = 1;
+  for (int i = 0; i < a.nseg; ++i) {
+    a.seg[i].A = segs[i]->W; a.seg[i].a_bs = 0; a.seg[i].lda = segs[i]->ldw;
+    a.seg[i].B = segs[i]->X; a.seg[i].b_bs = segs[i]->x_bs; a.seg[i].ldb = c.w.P;
+    a.seg[i].K = segs[i]->K;
+    if (segs[i]->w_trans != s0.w_trans) return fail(DPPM_E_INVALID, "linear: segments must share the weight orientation");
+    if (!aligned16(segs[i]->W) || segs[i]->ldw % 4 != 0) a.a_vec = 0;
+  }
+  a.b_vec = 1;   // planes are 16-byte aligned by construction (P % 4 == 0, workspace 256-byte aligned)
+  a.M = M; a.N = c.w.P;
+  a.C = Y; a.c_bs = y_bs; a.ldc = c.w.P;
+  a.bias = bias; a.act = act;
+  a.mul = mulmask; a.mul_bs = c.w.P; a.mul_ld = 0; a.mul_div = 1;
+  a.dact = dact; a.dact_bs = dact_bs;
+  a.accumulate = accumulate ? 1 : 0;
+  return launch_gemm(a, c.w.B, /*a_kmajor=*/s0.w_trans, /*b_kmajor=*/true, c.st);
+}
+
+// dW (M x Nw, pitch ldo) = sum_b dY[b] (M x P) * X[b]^T (P x Nw) ; optional db = row sums of dY
+int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
+  const Layout& w = c.w;
+  const int nsplit = wgrad_nsplit(w.B, w.P), kchunk = wgrad_kchunk(w.B, w.P);
+  const int nz = w.B * nsplit;
+  if ((size_t)nz * M * Nw > w.slab_floats) return fail(DPPM_E_INVALID, "wgrad: slab buffer too small");
+  GemmArgs a = base_args();
+  a.seg[0].A = dY; a.seg[0].a_bs = dy_bs; a.seg[0].lda = w.P;
+  a.seg[0].B = X; a.seg[0].b_bs = x_bs; a.seg[0].ldb = w.P;
+  a.seg[0].K = w.P;
+  a.a_vec = 1; a.b_vec = 1;
+  a.nsplit = nsplit; a.kchunk = kchunk;
+  a.M = M; a.N = Nw;
+  a.C = c.at(w.slabs); a.c_bs = (long)M * Nw; a.ldc = Nw;
+  a.rowsum = db ? c.at(w.rsum) : nullptr;
+  DPPM_TRY(launch_gemm(a, nz, false, false, c.st));
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, 256)), dim3(256), 0, c.st, c.at(w.slabs), nz, M, Nw, dW, ldo);
+  DPPM_TRY(check_launch("reduce_slabs(dW)"));
+  if (db) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(M, 256)), dim3(256), 0, c.st, c.at(w.rsum), nz, 1, M, db, M);
+    DPPM_TRY(check_launch("reduce_slabs(db)"));
+  }
+  return DPPM_OK;
+}
+
+// per-plane products for all (b,c): C = op(A) * op(B) * inv_norm[b] (* mask[b])
+int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batch, int n, int ld, bool ta, bool tb,
+             const float* scale, const float* mask, int div) {
+  GemmArgs a = base_args();
+  const long P = (long)n * ld;
+  a.seg[0].A = A; a.seg[0].a_bs = P; a.seg[0].lda = ld;
+  a.seg[0].B = Bm; a.seg[0].b_bs = P; a.seg[0].ldb = ld;
+  a.seg[0].K = n;
+  a.a_vec = aligned16(A); a.b_vec = aligned16(Bm);
+  a.M = n; a.N = n;
+  a.C = C; a.c_bs = P; a.ldc = ld;
+  a.scale = scale; a.scale_div = div;
+  a.mul = mask; a.mul_bs = P; a.mul_ld = ld; a.mul_div = div;
+  // op(A) = A   : element (m,k) at A[m*ld + k]  -> K-minor ;  op(A) = A^T : (m,k) at A[k*ld + m] -> K-major
+  // op(B) = B   : element (k,n) at B[k*ld + n]  -> K-major ;  op(B) = B^T : (k,n) at B[n*ld + k] -> K-minor
+  const bool a_kmajor = ta, b_kmajor = !tb;
+  return launch_gemm(a, batch, a_kmajor, b_kmajor, st);
+}
+
+int check_params(const dppm_ppgn_params* p, const char* who) {
+  DPPM_REQUIRE(p, "%s: null params", who);
+  DPPM_REQUIRE(p->num_layers >= 1 && p->num_layers <= 64, "%s: num_layers=%d", who, p->num_layers);
+  DPPM_REQUIRE(p->hidden >= 4 && p->hidden % 4 == 0, "%s: hidden=%d must be a positive multiple of 4", who, p->hidden);
+  DPPM_REQUIRE(p->in_w && p->in_b && p->cat_w && p->cat_b && p->after_w && p->after_b && p->final_w && p->final_b && p->layers_host,
+               "%s: null parameter pointer", who);
+  for (int l = 0; l < p->num_layers; ++l) {
+    const dppm_ppgn_layer& q = p->layers_host[l];
+    DPPM_REQUIRE(q.m1_w0 && q.m1_b0 && q.m1_w1 && q.m1_b1 && q.m2_w0 && q.m2_b0 && q.m2_w1 && q.m2_b1 && q.m4_w && q.m4_b,
+                 "%s: null parameter pointer in layer %d", who, l);
+  }
+  return DPPM_OK;
+}
+
+}  // namespace
+}  // namespace dppm
+
+using namespace dppm;
+
+extern "C" size_t dppm_ppgn_workspace_bytes(int B, int N, int H, int L, int training) {
+  if (B <= 0 || N <= 0 || H <= 0 || L <= 0) return 0;
+  return make_layout(B, N, H, L, training).total * sizeof(float);
+}
+
+extern "C" int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int n, int ld, int trans_a, int trans_b,
+                                 const float* scale, const float* mask, int scale_div, void* stream) {
+  DPPM_REQUIRE(A && Bm && C, "dppm_plane_matmul: null pointer");
+  DPPM_REQUIRE(batch > 0 && n > 0 && ld >= n && ld % 4 == 0, "dppm_plane_matmul: batch=%d n=%d ld=%d", batch, n, ld);
+  DPPM_REQUIRE(!(trans_a && trans_b), "dppm_plane_matmul: A^T * B^T is not provided");
+  DPPM_REQUIRE(scale_div >= 1, "dppm_plane_matmul: scale_div=%d", scale_div);
+  return plane_mm(as_stream(stream), A, Bm, C, batch, n, ld, trans_a != 0, trans_b != 0, scale, mask, scale_div);
+}
+
+extern "C" int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, float* u, long u_bs, int B, int C, int P,
+                              float* mean_out, float* rstd_out, void* stream) {
+  DPPM_REQUIRE(y && maskp && u, "dppm_inorm_fwd: null pointer");
+  DPPM_REQUIRE(B > 0 && C > 0 && P > 0 && P % 4 == 0 && y_bs % 4 == 0 && u_bs % 4 == 0, "dppm_inorm_fwd: B=%d C=%d P=%d", B, C, P);
+  DPPM_REQUIRE(aligned16(y) && aligned16(maskp) && aligned16(u), "dppm_inorm_fwd: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(inorm_fwd_kernel, dim3(B * C), dim3(NORM_THREADS), 0, as_stream(stream), y, y_bs, maskp, u, u_bs, C, P,
+                     mean_out, rstd_out);
+  return check_launch("dppm_inorm_fwd");
+}
+
+extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B,
+                                 int N, float* logits, void* workspace, size_t workspace_bytes, int training, void* stream) {
+  DPPM_TRY(check_params(pr, "dppm_ppgn_forward"));
+  DPPM_REQUIRE(A && mask && sigma && logits && workspace, "dppm_ppgn_forward: null pointer");
+  DPPM_REQUIRE(B > 0 && N > 0, "dppm_ppgn_forward: B=%d N=%d must be positive", B, N);
+  DPPM_REQUIRE(((uintptr_t)workspace & 255) == 0, "dppm_ppgn_forward: workspace must be 256-byte aligned");
+  const int H = pr->hidden, L = pr->num_layers;
+  Ctx c{as_stream(stream), make_layout(B, N, H, L, training), static_cast<float*>(workspace)};
+  const Layout& w = c.w;
+  DPPM_REQUIRE(workspace_bytes >= w.total * sizeof(float), "dppm_ppgn_forward: workspace %zu < %zu bytes", workspace_bytes,
+               w.total * sizeof(float));
+  const int P = w.P;
+  const long cat_bs = (long)w.CT * P, hs = (long)H * P;
+  float* maskp = c.at(w.maskp);
+  float* cat = c.at(w.cat);
+
+  hipLaunchKernelGGL(prep_kernel, dim3(cdiv(P, 256) < 64 ? cdiv(P, 256) : 64, B), dim3(256), 0, c.st, A, mask, sigma, N, w.ld,
+                     w.CT, cat, maskp, c.at(w.inv_norm));
+  DPPM_TRY(check_launch("prep"));
+
+  // in_lin: u0 = W_in (H x 2) * [A ; sigma I] + b     (model/ppgn.py:301)
+  DPPM_TRY(linear(c, H, LinArgs{pr->in_w, 2, false, cat, cat_bs, 2}, nullptr, pr->in_b, 0, nullptr, nullptr, 0, c.at(w.u0), hs, false));
+
+  for (int l = 0; l < L; ++l) {
+    const dppm_ppgn_layer& q = pr->layers_host[l];
+    const float* x = l == 0 ? c.at(w.u0) : cat + (size_t)(2 + (l - 1) * H) * P;
+    const long x_bs = l == 0 ? hs : cat_bs;
+    float* hid1 = training ? c.at(w.hid1) + (size_t)l * w.S : c.at(w.tmp[0]);
+    float* hid2 = training ? c.at(w.hid2) + (size_t)l * w.S : c.at(w.tmp[0]);
+    float* o1 = training ? c.at(w.o1) + (size_t)l * w.S : c.at(w.tmp[1]);
+    float* o2 = training ? c.at(w.o2) + (size_t)l * w.S : c.at(w.tmp[2]);
+    float* mm = training ? c.at(w.mm) + (size_t)l * w.S : c.at(w.tmp[0]);
+    float* y = c.at(w.tmp[3]);
+    // m1, m2: Linear -> LeakyReLU -> Linear, then * mask   (model/ppgn.py:58-59)
+    DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
+    DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, false, hid1, hs, H}, nullptr, q.m1_b1, 0, maskp, nullptr, 0, o1, hs, false));
+    DPPM_TRY(linear(c, H, LinArgs{q.m2_w0, H, false, x, x_bs, H}, nullptr, q.m2_b0, 1, nullptr, nullptr, 0, hid2, hs, false));
+    DPPM_TRY(linear(c, H, LinArgs{q.m2_w1, H, false, hid2, hs, H}, nullptr, q.m2_b1, 0, maskp, nullptr, 0, o2, hs, false));
+    // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
+    DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H));
+    // m4 on cat(mm, x)   (model/ppgn.py:66-69)
+    LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
+    DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
+    // masked instance norm, * mask; result lands in its slot of CAT   (model/ppgn.py:307,315-316)
+    hipLaunchKernelGGL(inorm_fwd_kernel, dim3(B * H), dim3(NORM_THREADS), 0, c.st, y, hs, maskp, cat + (size_t)(2 + l * H) * P,
+                       cat_bs, H, P, (float*)nullptr, c.at(w.rstd) + (size_t)l * B * H);
+    DPPM_TRY(check_launch("inorm_fwd"));
+  }
+  // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)
+  DPPM_TRY(linear(c, H, LinArgs{pr->cat_w, w.CT, false, cat, cat_bs, w.CT}, nullptr, pr->cat_b, 0, nullptr, nullptr, 0, c.at(w.R), hs, false));
+  // out + LeakyReLU(after_conv(out)) ; final_lin   (model/ppgn.py:331-333)
+  DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, false, c.at(w.R), hs, H}, nullptr, pr->after_b, 1, nullptr, nullptr, 0, c.at(w.act), hs, false));
+  hipLaunchKernelGGL(final_fwd_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, c.st, c.at(w.R), c.at(w.act), pr->final_w, pr->final_b,
+                     H, N, w.ld, logits);
+  return check_launch("final_fwd");
+}
+
+extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_params* gr, const float* A, const float* mask,
+                                  const float* sigma, int B, int N, const float* dlogits, float* dsigma, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  (void)A; (void)mask; (void)sigma;
+  DPPM_TRY(check_params(pr, "dppm_ppgn_backward(params)"));
+  DPPM_TRY(check_params(gr, "dppm_ppgn_backward(grads)"));
+  DPPM_REQUIRE(dlogits && workspace, "dppm_ppgn_backward: null pointer");
+  DPPM_REQUIRE(B > 0 && N > 0, "dppm_ppgn_backward: B=%d N=%d must be positive", B, N);
+  DPPM_REQUIRE(gr->hidden == pr->hidden && gr->num_layers == pr->num_layers, "dppm_ppgn_backward: grads/params shape mismatch");
+  if (dsigma) return fail(DPPM_E_UNSUPPORTED, "dppm_ppgn_backward: dsigma is not implemented yet");
+  const int H = pr->hidden, L = pr->num_layers;
+  Ctx c{as_stream(stream), make_layout(B, N, H, L, 1), static_cast<float*>(workspace)};
+  const Layout& w = c.w;
+  DPPM_REQUIRE(workspace_bytes >= w.total * sizeof(float), "dppm_ppgn_backward: workspace %zu < %zu bytes", workspace_bytes,
+               w.total * sizeof(float));
+  const int P = w.P;
+  const long cat_bs = (long)w.CT * P, hs = (long)H * P;
+  float* maskp = c.at(w.maskp);
+  float* cat = c.at(w.cat);
+  float* dcat = c.at(w.dcat);
+  float* dh = c.at(w.dh);
+  float* dz = c.at(w.dz);
+  float* dy = c.at(w.dy);
+  float* dmm = c.at(w.dmm);
+  float* do1 = c.at(w.do1);
+  float* do2 = c.at(w.do2);
+  float* du0 = c.at(w.du0);
+  float* part = c.at(w.rsum) + (size_t)B * wgrad_nsplit(B, P) * H;   // [B*H] + [B]
+
+  // head: final_lin and after_conv
+  hipLaunchKernelGGL(final_bwd_kernel, dim3(B * H), dim3(256), 0, c.st, c.at(w.R), c.at(w.act), pr->final_w, dlogits, H, N, w.ld,
+                     dh, dz, part, part + (size_t)B * H);
+  DPPM_TRY(check_launch("final_bwd"));
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(H, 256)), dim3(256), 0, c.st, part, B, 1, H, gr->final_w, H);
+  DPPM_TRY(check_launch("reduce(dwfin)"));
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(256), 0, c.st, part + (size_t)B * H, B, 1, 1, gr->final_b, 1);
+  DPPM_TRY(check_launch("reduce(dbfin)"));
+  DPPM_TRY(wgrad(c, H, dz, hs, H, c.at(w.R), hs, gr->after_w, H, gr->after_b));
+  // dR = dh + W_ac^T dz   (accumulated into dh)
+  DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, true, dz, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dh, hs, true));
+  // layer_cat_lin
+  DPPM_TRY(wgrad(c, H, dh, hs, w.CT, cat, cat_bs, gr->cat_w, w.CT, gr->cat_b));
+  DPPM_TRY(linear(c, w.CT, LinArgs{pr->cat_w, w.CT, true, dh, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dcat, cat_bs, false));
+
+  for (int l = L - 1; l >= 0; --l) {
+    const dppm_ppgn_layer& q = pr->layers_host[l];
+    const dppm_ppgn_layer& gq = gr->layers_host[l];
+    const float* x = l == 0 ? c.at(w.u0) : cat + (size_t)(2 + (l - 1) * H) * P;
+    const long x_bs = l == 0 ? hs : cat_bs;
+    float* dx = l == 0 ? du0 : dcat + (size_t)(2 + (l - 1) * H) * P;
+    const long dx_bs = l == 0 ? hs : cat_bs;
+    const float* hid1 = c.at(w.hid1) + (size_t)l * w.S;
+    const float* hid2 = c.at(w.hid2) + (size_t)l * w.S;
+    const float* o1 = c.at(w.o1) + (size_t)l * w.S;
+    const float* o2 = c.at(w.o2) + (size_t)l * w.S;
+    const float* mm = c.at(w.mm) + (size_t)l * w.S;
+    // instance norm
+    hipLaunchKernelGGL(inorm_bwd_kernel, dim3(B * H), dim3(NORM_THREADS), 0, c.st, dcat + (size_t)(2 + l * H) * P, cat_bs,
+                       cat + (size_t)(2 + l * H) * P, cat_bs, maskp, c.at(w.rstd) + (size_t)l * B * H, dy, H, P);
+    DPPM_TRY(check_launch("inorm_bwd"));
+    // m4
+    DPPM_TRY(wgrad(c, H, dy, hs, H, mm, hs, gq.m4_w, 2 * H, gq.m4_b));
+    DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gq.m4_w + H, 2 * H, nullptr));
+    DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dmm, hs, false));
+    DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));
+    // contraction: do1 = dmm o2^T / sqrt(n) * mask ; do2 = o1^T dmm / sqrt(n) * mask
+    DPPM_TRY(plane_mm(c.st, dmm, o2, do1, B * H, N, w.ld, false, true, c.at(w.inv_norm), maskp, H));
+    DPPM_TRY(plane_mm(c.st, o1, dmm, do2, B * H, N, w.ld, true, false, c.at(w.inv_norm), maskp, H));
+    // m1 (dy is free again: reuse it for the pre-activation gradient)
+    float* dpre = dy;
+    DPPM_TRY(wgrad(c, H, do1, hs, H, hid1, hs, gq.m1_w1, H, gq.m1_b1));
+    DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, true, do1, hs, H}, nullptr, nullptr, 0, nullptr, hid1, hs, dpre, hs, false));
+    DPPM_TRY(wgrad(c, H, dpre, hs, H, x, x_bs, gq.m1_w0, H, gq.m1_b0));
+    DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, true, dpre, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, true));
+    // m2
+    DPPM_TRY(wgrad(c, H, do2, hs, H, hid2, hs, gq.m2_w1, H, gq.m2_b1));
+    DPPM_TRY(linear(c, H, LinArgs{q.m2_w1, H, true, do2, hs, H}, nullptr, nullptr, 0, nullptr, hid2, hs, dpre, hs, false));
+    DPPM_TRY(wgrad(c, H, dpre, hs, H, x, x_bs, gq.m2_w0, H, gq.m2_b0));
+    DPPM_TRY(linear(c, H, LinArgs{q.m2_w0, H, true, dpre, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, true));
+  }
+  // in_lin
+  DPPM_TRY(wgrad(c, H, du0, hs, 2, cat, cat_bs, gr->in_w, 2, gr->in_b));
+  return DPPM_OK;
+}

@@ -1,0 +1,267 @@
+"""Torch-tensor front end of the C-ABI (include/dppm_hip.h).  torch is used only as the owner of device memory and
+of the current HIP stream; every function validates its operands on the host (shape, dtype, device, contiguity)
+before a raw pointer reaches a kernel, and raises RuntimeError on a non-zero status.  No CPU path exists."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import PpgnLayer, PpgnParams, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, shape=None, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the DDPM hot path runs on the GPU only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _rng_args(U, seed, graph_id0, offset, shape):
+    if U is not None:
+        _chk(U, "U", shape)
+    return _ptr(U), C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(graph_id0)), C.c_uint32(int(offset))
+
+
+def _f32c(t):
+    return t.to(torch.float32).contiguous()
+
+
+def generate_mask(flags):
+    flags = _chk(_f32c(flags), "flags")
+    B, N = flags.shape
+    mask = torch.empty(B, N, N, device=flags.device, dtype=torch.float32)
+    check(lib.dppm_generate_mask(_ptr(flags), B, N, _ptr(mask), _stream()), "dppm_generate_mask")
+    return mask
+
+
+def _sigma_args(sigma, B, device):
+    """python float -> scalar path; sequence / array / tensor of B doubles -> device array."""
+    if isinstance(sigma, (float, int, np.floating)):
+        return None, float(sigma)
+    s = torch.as_tensor(np.asarray(sigma, dtype=np.float64) if not isinstance(sigma, torch.Tensor) else sigma)
+    s = s.to(device=device, dtype=torch.float64).contiguous().view(-1)
+    if s.numel() != B:
+        raise ValueError(f"sigma: {s.numel()} values for a batch of {B} graphs")
+    return s, 0.0
+
+
+def edgeflip(A0, flags, sigma, U=None, seed=0, graph_id0=0, offset=0, want_target=True, out=None):
+    """q(A_t|A_0): returns (A_t, target).  sigma: python float (all graphs) or B values (one per graph)."""
+    A0 = _chk(A0, "A0")
+    B, N, _ = A0.shape
+    flags = _chk(flags, "flags", (B, N))
+    sig_dev, sig_scalar = _sigma_args(sigma, B, A0.device)
+    A_t = out if out is not None else torch.empty_like(A0)
+    _chk(A_t, "out", (B, N, N))
+    target = torch.empty_like(A0) if want_target else None
+    u, sd, g0, off = _rng_args(U, seed, graph_id0, offset, (B, N, N))
+    check(lib.dppm_edgeflip_fwd(_ptr(A0), _ptr(flags), _ptr(sig_dev), C.c_double(sig_scalar), u, sd, g0, off, B, N,
+                                _ptr(A_t), _ptr(target), _stream()), "dppm_edgeflip_fwd")
+    return A_t, target
+
+
+def init_xT(flags, U=None, seed=0, graph_id0=0, offset=0):
+    flags = _chk(flags, "flags")
+    B, N = flags.shape
+    out = torch.empty(B, N, N, device=flags.device, dtype=torch.float32)
+    u, sd, g0, off = _rng_args(U, seed, graph_id0, offset, (B, N, N))
+    check(lib.dppm_init_xT(_ptr(flags), u, sd, g0, off, B, N, _ptr(out), _stream()), "dppm_init_xT")
+    return out
+
+
+def reverse_step_simple(A_t, logits, flags, U=None, seed=0, graph_id0=0, offset=0, is_probs=False, out=None):
+    A_t = _chk(A_t, "A_t")
+    B, N, _ = A_t.shape
+    logits = _chk(logits, "logits", (B, N, N))
+    flags = _chk(flags, "flags", (B, N))
+    out = out if out is not None else torch.empty_like(A_t)
+    _chk(out, "out", (B, N, N))
+    u, sd, g0, off = _rng_args(U, seed, graph_id0, offset, (B, N, N))
+    check(lib.dppm_reverse_step_simple(_ptr(A_t), _ptr(logits), int(bool(is_probs)), _ptr(flags), u, sd, g0, off, B, N,
+                                       _ptr(out), _stream()), "dppm_reverse_step_simple")
+    return out
+
+
+def reverse_step_vlb(A_t, logits, flags, sigmatilde_t, beta_t, sigmatilde_t1, U=None, seed=0, graph_id0=0, offset=0,
+                     is_probs=False, out=None):
+    A_t = _chk(A_t, "A_t")
+    B, N, _ = A_t.shape
+    logits = _chk(logits, "logits", (B, N, N))
+    flags = _chk(flags, "flags", (B, N))
+    out = out if out is not None else torch.empty_like(A_t)
+    _chk(out, "out", (B, N, N))
+    u, sd, g0, off = _rng_args(U, seed, graph_id0, offset, (B, N, N))
+    check(lib.dppm_reverse_step_vlb(_ptr(A_t), _ptr(logits), int(bool(is_probs)), _ptr(flags), C.c_double(sigmatilde_t),
+                                    C.c_double(beta_t), C.c_double(sigmatilde_t1), u, sd, g0, off, B, N, _ptr(out),
+                                    _stream()), "dppm_reverse_step_vlb")
+    return out
+
+
+def _loss_ws(B, N, device):
+    n = lib.dppm_loss_workspace_bytes(B, N)
+    return torch.empty(max(n, 8) // 8, device=device, dtype=torch.float64), n
+
+
+def loss_bce(score, target, sigmas, mask, B_global=None, want_grad=True):
+    """returns (loss [float64 0-d tensor on device], dscore or None)."""
+    score = _chk(score, "score")
+    B, N, _ = score.shape
+    target = _chk(target, "target", (B, N, N))
+    mask = _chk(mask, "mask", (B, N, N))
+    sig_dev, _ = _sigma_args(list(sigmas) if not isinstance(sigmas, torch.Tensor) else sigmas, B, score.device)
+    ws, nbytes = _loss_ws(B, N, score.device)
+    loss = torch.empty((), device=score.device, dtype=torch.float64)
+    dscore = torch.empty_like(score) if want_grad else None
+    check(lib.dppm_loss_bce_fwd_bwd(_ptr(score), _ptr(target), _ptr(sig_dev), _ptr(mask), B, N, int(B_global or B), _ptr(loss),
+                                    _ptr(dscore), _ptr(ws), C.c_size_t(nbytes), _stream()), "dppm_loss_bce_fwd_bwd")
+    return loss, dscore
+
+
+def loss_vlb(score, A_t, A_0, sched, mask, want_grad=True):
+    """sched: [B,3] doubles (sigmatilde_t, beta_t, sigmatilde_{t-1}).  returns (loss float32 0-d, dscore or None)."""
+    score = _chk(score, "score")
+    B, N, _ = score.shape
+    A_t = _chk(A_t, "A_t", (B, N, N))
+    A_0 = _chk(A_0, "A_0", (B, N, N))
+    mask = _chk(mask, "mask", (B, N, N))
+    sched = torch.as_tensor(np.asarray(sched, dtype=np.float64) if not isinstance(sched, torch.Tensor) else sched)
+    sched = _chk(sched.to(device=score.device, dtype=torch.float64).contiguous(), "sched", (B, 3), torch.float64)
+    ws, nbytes = _loss_ws(B, N, score.device)
+    loss = torch.empty((), device=score.device, dtype=torch.float32)
+    dscore = torch.empty_like(score) if want_grad else None
+    check(lib.dppm_loss_vlb_fwd_bwd(_ptr(score), _ptr(A_t), _ptr(A_0), _ptr(sched), _ptr(mask), B, N, _ptr(loss), _ptr(dscore),
+                                    _ptr(ws), C.c_size_t(nbytes), _stream()), "dppm_loss_vlb_fwd_bwd")
+    return loss, dscore
+
+
+# ------------------------------------------------------------------------------------------------- PPGN
+LAYER_FIELDS = (("m1_w0", "m1.0.weight"), ("m1_b0", "m1.0.bias"), ("m1_w1", "m1.2.weight"), ("m1_b1", "m1.2.bias"),
+                ("m2_w0", "m2.0.weight"), ("m2_b0", "m2.0.bias"), ("m2_w1", "m2.2.weight"), ("m2_b1", "m2.2.bias"),
+                ("m4_w", "m4.0.weight"), ("m4_b", "m4.0.bias"))
+TOP_FIELDS = (("in_w", "in_lin.0.weight"), ("in_b", "in_lin.0.bias"), ("cat_w", "layer_cat_lin.0.weight"),
+              ("cat_b", "layer_cat_lin.0.bias"), ("after_w", "after_conv.0.weight"), ("after_b", "after_conv.0.bias"),
+              ("final_w", "final_lin.0.weight"), ("final_b", "final_lin.0.bias"))
+
+
+def used_param_names(num_layers):
+    names = [n for _, n in TOP_FIELDS[:2]]
+    for l in range(num_layers):
+        names += [f"convs.{l}.{n}" for _, n in LAYER_FIELDS]
+    names += [n for _, n in TOP_FIELDS[2:]]
+    return names
+
+
+def expected_shapes(num_layers, H):
+    sh = {"in_lin.0.weight": (H, 2), "in_lin.0.bias": (H,), "layer_cat_lin.0.weight": (H, num_layers * H + 2),
+          "layer_cat_lin.0.bias": (H,), "after_conv.0.weight": (H, H), "after_conv.0.bias": (H,),
+          "final_lin.0.weight": (1, H), "final_lin.0.bias": (1,)}
+    for l in range(num_layers):
+        for m in ("m1", "m2"):
+            for k in ("0", "2"):
+                sh[f"convs.{l}.{m}.{k}.weight"] = (H, H)
+                sh[f"convs.{l}.{m}.{k}.bias"] = (H,)
+        sh[f"convs.{l}.m4.0.weight"] = (H, 2 * H)
+        sh[f"convs.{l}.m4.0.bias"] = (H,)
+    return sh
+
+
+class ParamPack:
+    """Host-side dppm_ppgn_params built from a {state_dict name: cuda tensor} mapping.  Keeps the tensors alive."""
+
+    def __init__(self, tensors, num_layers, hidden):
+        shapes = expected_shapes(num_layers, hidden)
+        self.tensors = {}
+        for name, shape in shapes.items():
+            if name not in tensors:
+                raise KeyError(f"missing PPGN parameter {name}")
+            self.tensors[name] = _chk(tensors[name], name, shape)
+        self.layers = (PpgnLayer * num_layers)()
+        for l in range(num_layers):
+            for field, suffix in LAYER_FIELDS:
+                setattr(self.layers[l], field, self.tensors[f"convs.{l}.{suffix}"].data_ptr())
+        self.struct = PpgnParams()
+        self.struct.num_layers = num_layers
+        self.struct.hidden = hidden
+        for field, name in TOP_FIELDS:
+            setattr(self.struct, field, self.tensors[name].data_ptr())
+        self.struct.layers_host = C.cast(self.layers, C.POINTER(PpgnLayer))
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def ppgn_workspace(B, N, H, L, training, device):
+    nbytes = lib.dppm_ppgn_workspace_bytes(B, N, H, L, int(bool(training)))
+    if nbytes == 0:
+        raise ValueError(f"invalid PPGN geometry B={B} N={N} H={H} L={L}")
+    return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+
+
+def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None):
+    A = _chk(A, "A")
+    B, N, _ = A.shape
+    mask = _chk(mask, "mask", (B, N, N))
+    sigma = _chk(sigma, "sigma", (B,))
+    _chk(workspace, "workspace")
+    logits = out if out is not None else torch.empty(B, N, N, device=A.device, dtype=torch.float32)
+    _chk(logits, "out", (B, N, N))
+    check(lib.dppm_ppgn_forward(pack.ref(), _ptr(A), _ptr(mask), _ptr(sigma), B, N, _ptr(logits), _ptr(workspace),
+                                C.c_size_t(workspace.numel() * 4), int(bool(training)), _stream()), "dppm_ppgn_forward")
+    return logits
+
+
+def ppgn_backward(pack, grad_pack, A, mask, sigma, dlogits, workspace):
+    A = _chk(A, "A")
+    B, N, _ = A.shape
+    dlogits = _chk(dlogits, "dlogits", (B, N, N))
+    check(lib.dppm_ppgn_backward(pack.ref(), grad_pack.ref(), _ptr(A), _ptr(mask), _ptr(sigma), B, N, _ptr(dlogits),
+                                 C.c_void_p(0), _ptr(workspace), C.c_size_t(workspace.numel() * 4), _stream()),
+          "dppm_ppgn_backward")
+
+
+def plane_matmul(A, Bm, n, trans_a=False, trans_b=False, scale=None, mask=None, scale_div=1):
+    """A, Bm: [batch, n, ld] planes (ld = n rounded up to 4)."""
+    A = _chk(A, "A")
+    batch, n_, ld = A.shape
+    if n_ != n:
+        raise ValueError("plane_matmul: A must be [batch, n, ld]")
+    Bm = _chk(Bm, "Bm", (batch, n, ld))
+    out = torch.zeros_like(A)
+    check(lib.dppm_plane_matmul(_ptr(A), _ptr(Bm), _ptr(out), batch, n, ld, int(trans_a), int(trans_b), _ptr(scale), _ptr(mask),
+                                int(scale_div), _stream()), "dppm_plane_matmul")
+    return out
+
+
+def inorm_fwd(y, maskp):
+    """y: [B, C, P], maskp: [B, P] -> (u, mean [B,C], rstd [B,C])."""
+    y = _chk(y, "y")
+    B, Cc, P = y.shape
+    maskp = _chk(maskp, "maskp", (B, P))
+    u = torch.empty_like(y)
+    mean = torch.empty(B, Cc, device=y.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(lib.dppm_inorm_fwd(_ptr(y), C.c_long(Cc * P), _ptr(maskp), _ptr(u), C.c_long(Cc * P), B, Cc, P, _ptr(mean), _ptr(rstd),
+                             _stream()), "dppm_inorm_fwd")
+    return u, mean, rstd
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, n, (param.numel(),))
+    check(lib.dppm_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), C.c_size_t(param.numel()), lr, beta1,
+                             beta2, eps, weight_decay, int(step), grad_scale, _stream()), "dppm_adam_step")

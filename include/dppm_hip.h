@@ -1,0 +1,179 @@
+/*
+ * dppm_hip.h -- C-ABI of libdppm_hip.so: the MI355X (gfx950) implementation of the discrete
+ * graph-DDPM hot path of kilianhae/discrete_DPPM_Graphs.
+ *
+ * The reference has no FFI for this path (it is eager PyTorch); each entry point below names the reference
+ * Python function (file:line under the reference tree) whose device work it replaces.  The Python host
+ * side (discrete_dppm_graphs_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; buffers are owned by the caller;
+ *     no entry point allocates or frees device memory, synchronises the device, or keeps state between calls;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued on it;
+ *   - return value: 0 = ok, <0 = error (DPPM_E_*); dppm_last_error() gives a thread-local message;
+ *   - public tensors are dense row-major float32: adjacency / mask / logits / uniforms [B][N][N], flags [B][N];
+ *   - {0,1}-valued tensors (A_0, A_t, flags, mask, targets) are float32 as in the reference;
+ *   - activations inside the PPGN workspace are channel-first planes [B][C][N][ld], ld = N rounded up to 4.
+ *
+ * Random numbers: every sampling entry point takes either explicit uniforms U[B][N][N] (what torch.bernoulli
+ * would have drawn; only i<j is read) or, when U == NULL, draws them itself from Philox4x32-10 with
+ *   u(b,i,j) = (philox(key = seed, ctr = (i, j, graph_id0 + b, offset)).x >> 8) * 2^-24 .
+ * graph_id0 is the GLOBAL index of the shard's first graph, so samples do not depend on batch or GPU count.
+ */
+#ifndef DPPM_HIP_H
+#define DPPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPPM_OK 0
+#define DPPM_E_INVALID (-1)   /* bad argument (null pointer, size <= 0, workspace too small, ...) */
+#define DPPM_E_LAUNCH (-2)    /* HIP reported a launch / runtime error */
+#define DPPM_E_UNSUPPORTED (-3)
+
+const char* dppm_last_error(void);
+/* ABI version, bumped on any signature change. */
+int dppm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Diffusion ops (bit-exact float32 restatements; compiled with FP contraction off)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* mask[b][i][j] = (flags[b][i] >= 0.9) * (flags[b][j] >= 0.9).
+ * Replaces utils/graph_utils.py:312-319 generate_mask (a Python triple loop on the CPU). */
+int dppm_generate_mask(const float* flags, int B, int N, float* mask, void* stream);
+
+/* q(A_t | A_0):  p = A0 > 1/2 ? 1 - sigma : sigma ; up = bernoulli(p) for i<j ; A_t = sym(up) * f_i * f_j ;
+ * target = |A_t_unmasked - A0| * f_i * f_j.   sigma_dev: [B] doubles on the device (a sigma per graph, as
+ * gen_list_of_data_single does) or NULL to use sigma_scalar for every graph (as the samplers do).
+ * (1 - sigma) is formed in double and rounded once to float, like torch.full_like(x, 1 - sigma).
+ * target may be NULL.  A_t may alias A0.
+ * Replaces utils/graph_utils.py:155-165 discretenoise, :236-246 discretenoise_single, :96-138
+ * gen_list_of_data_single (the loop over graphs) and :7-19 mask_adjs. */
+int dppm_edgeflip_fwd(const float* A0, const float* flags, const double* sigma_dev, double sigma_scalar,
+                      const float* U, uint64_t seed, uint32_t graph_id0, uint32_t offset,
+                      int B, int N, float* A_t, float* target, void* stream);
+
+/* x_T = sym(triu(bernoulli(1/2 where both nodes active), 1)).
+ * Replaces sample_ppgn_simple.py:31-41 / sample_ppgn_vlb.py:51-62 (gen_init_data's Python loop + bernoulli). */
+int dppm_init_xT(const float* flags, const float* U, uint64_t seed, uint32_t graph_id0, uint32_t offset,
+                 int B, int N, float* A_T, void* stream);
+
+/* One reverse step of the "simple" sampler after the denoiser:
+ *   r = sigmoid(logits) (or r = logits when is_probs != 0); r = (r + r^T)/2 * mask; F = sym(triu(bernoulli(r),1));
+ *   out = A_t XOR F.            out may alias A_t.
+ * Replaces sample_ppgn_simple.py:58-68 (take_step after the model call). */
+int dppm_reverse_step_simple(const float* A_t, const float* logits, int is_probs, const float* flags,
+                             const float* U, uint64_t seed, uint32_t graph_id0, uint32_t offset,
+                             int B, int N, float* out, void* stream);
+
+/* One reverse step of the VLB sampler after the denoiser (posterior mix):
+ *   r = sym(sigmoid(logits)); s = A_t ? 1 - r : r;
+ *   p = (1-s) * m1 * st1 / d0 + s * m1 * (1-st1) / d1,  m1 = A_t ? 1-beta_t : beta_t,
+ *   d0 = A_t ? st : 1-st, d1 = A_t ? 1-st : st;  out = sym(triu(bernoulli(sym(p) * mask), 1)).
+ * sigmatilde_t, beta_t, sigmatilde_t1 are the python doubles of the schedule; the six float constants are
+ * formed in double and rounded once, as torch.where(cond, python_float, python_float) does.
+ * Replaces sample_ppgn_vlb.py:82-107 (take_step after the model call). */
+int dppm_reverse_step_vlb(const float* A_t, const float* logits, int is_probs, const float* flags,
+                          double sigmatilde_t, double beta_t, double sigmatilde_t1,
+                          const float* U, uint64_t seed, uint32_t graph_id0, uint32_t offset,
+                          int B, int N, float* out, void* stream);
+
+/* Workspace (bytes) for the two loss entry points below. */
+size_t dppm_loss_workspace_bytes(int B, int N);
+
+/* Simple loss, forward + gradient:  loss = sum_{b,i,j} sym(BCEwithLogits(score, target) * w_b) * mask / (B_global*N*N),
+ * w_b = 1 - 2 sigma_b + 1/B_global.   loss_out: one double on the device.  dscore (nullable): d loss / d score.
+ * B_global = number of graphs in the whole (possibly data-parallel) batch; this call handles B of them.
+ * Replaces ppgn_simple.py:25-34 loss_func_bce (+ its autograd backward). */
+int dppm_loss_bce_fwd_bwd(const float* score, const float* target, const double* sigma_dev, const float* mask,
+                          int B, int N, int B_global, double* loss_out, float* dscore,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* VLB loss, forward + gradient: sum over graphs and i != j of sym(KL(q || p)) * mask, with q the true posterior
+ * q(A_{t-1}=1 | A_t, A_0) and p the model posterior mix (see dppm_reverse_step_vlb).
+ * sched_dev: [B][3] doubles (sigmatilde_t, beta_t, sigmatilde_{t-1} = st - st/t) per graph.
+ * loss_out: one float on the device.   Replaces ppgn_vlb.py:79-125 loss_func_kld (+ autograd backward). */
+int dppm_loss_vlb_fwd_bwd(const float* score, const float* A_t, const float* A_0, const double* sched_dev,
+                          const float* mask, int B, int N, float* loss_out, float* dscore,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PPGN ("Powerful") denoiser, configuration built by utils/loading_utils.py:98-119
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Pointers to the used parameters, in the reference's own shapes (torch nn.Linear: weight [out][in] row-major).
+ * State-dict names in comments.  The same struct (with writable buffers) receives the gradients. */
+typedef struct dppm_ppgn_layer {
+  float* m1_w0; float* m1_b0;   /* convs.{l}.m1.0.{weight,bias}  [H][H], [H] */
+  float* m1_w1; float* m1_b1;   /* convs.{l}.m1.2.*              [H][H], [H] */
+  float* m2_w0; float* m2_b0;   /* convs.{l}.m2.0.* */
+  float* m2_w1; float* m2_b1;   /* convs.{l}.m2.2.* */
+  float* m4_w;  float* m4_b;    /* convs.{l}.m4.0.*              [H][2H], [H] */
+} dppm_ppgn_layer;
+
+typedef struct dppm_ppgn_params {
+  int32_t num_layers;           /* L */
+  int32_t hidden;               /* H = hidden = hidden_final */
+  float* in_w;  float* in_b;    /* in_lin.0.*         [H][2], [H] */
+  float* cat_w; float* cat_b;   /* layer_cat_lin.0.*  [H][L*H+2], [H] */
+  float* after_w; float* after_b; /* after_conv.0.*   [H][H], [H] */
+  float* final_w; float* final_b; /* final_lin.0.*    [1][H], [1] */
+  const dppm_ppgn_layer* layers_host; /* HOST array of L entries (entries hold device pointers) */
+} dppm_ppgn_params;
+
+/* Bytes of workspace dppm_ppgn_forward needs; with training != 0 it also keeps what dppm_ppgn_backward reads. */
+size_t dppm_ppgn_workspace_bytes(int B, int N, int H, int L, int training);
+
+/* logits[B][N][N] = Powerful.forward(node_features (ignored), A, mask, noiselevel) in eval() mode.
+ * sigma: [B] floats on the device (the reference passes one python float per call; a vector lets a whole
+ * training batch run in one call).  mask: [B][N][N], binary, node 0 of every graph active (the reference divides
+ * by sqrt(sum_j mask[b][0][j]), model/ppgn.py:51).
+ * Replaces model/ppgn.py:257-337 Powerful.forward/forward_cat, :47-71 PowerfulLayer.forward and
+ * util/model_helper.py:176-191 masked_instance_norm2D. */
+int dppm_ppgn_forward(const dppm_ppgn_params* params_host, const float* A, const float* mask, const float* sigma,
+                      int B, int N, float* logits, void* workspace, size_t workspace_bytes, int training,
+                      void* stream);
+
+/* Gradients of sum(logits * dlogits) w.r.t. every parameter in *grads_host (same layout as params; every
+ * buffer is overwritten).  `workspace` must be the one a dppm_ppgn_forward(training=1) call on the same inputs
+ * filled.  dsigma (nullable): [B] gradient w.r.t. sigma (needed only when noise_mlp conditions sigma).
+ * Replaces torch autograd over model/ppgn.py:257-337. */
+int dppm_ppgn_backward(const dppm_ppgn_params* params_host, const dppm_ppgn_params* grads_host,
+                       const float* A, const float* mask, const float* sigma, int B, int N,
+                       const float* dlogits, float* dsigma, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Building blocks, exported for tests and for callers that schedule layers themselves. */
+
+/* C[g] = epilogue(A[g] (MxK) * B[g] (KxN)) for g in [0,batch): the per-channel adjacency contraction
+ * (model/ppgn.py:62 `out1 @ out2`), planes [N][ld].  trans_a / trans_b select A^T / B^T (backward).
+ * scale (nullable): [batch / scale_div] multiplies the product; mask (nullable): [batch / scale_div][n][ld]
+ * multiplies it elementwise. */
+int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int n, int ld, int trans_a, int trans_b,
+                      const float* scale, const float* mask, int scale_div, void* stream);
+
+/* Masked instance norm over each [N][ld] plane (util/model_helper.py:176-191 + the `u * mask` of
+ * model/ppgn.py:315).  y, u: [B][C][N*ld] with batch strides y_bs / u_bs (floats); maskp: [B][N*ld];
+ * mean_out / rstd_out (nullable): [B][C]. */
+int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, float* u, long u_bs, int B, int C, int P,
+                   float* mean_out, float* rstd_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One fused Adam step over a flat parameter buffer (torch.optim.Adam semantics: betas, eps, L2 weight decay
+ * added to the gradient, bias correction with `step` starting at 1).  Replaces optimizer.step() at
+ * ppgn_simple.py:93 / ppgn_vlb.py:198 (optim.Adam built at ppgn_simple.py:259-262). */
+int dppm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPPM_HIP_H */

@@ -1,0 +1,227 @@
+"""GPU parity of the diffusion kernels (through the C-ABI) against the oracle and the reference-generated fixtures.
+Bit-exact for everything that is {0,1}-valued; tolerances are stated where floating point sums are compared."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from discrete_dppm_graphs_amd import ops
+    return ops
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype).cuda().contiguous()
+
+
+def rand_graphs(rng, B, N, ragged=True):
+    A = np.zeros((B, N, N), np.float32)
+    for b in range(B):
+        n = int(rng.integers(max(2, N // 2), N + 1)) if ragged else N
+        up = np.triu((rng.random((n, n)) < 0.3).astype(np.float32), 1)
+        for i in range(n - 1):
+            up[i, i + 1] = 1
+        A[b, :n, :n] = up + up.T
+    flags = (A.sum(-1) > 1e-5).astype(np.float32)
+    return A, flags
+
+
+# ------------------------------------------------------------------ golden fixtures (reference's own outputs)
+def test_mask_golden(ops):
+    g = load("g2_flip.npz")
+    assert np.array_equal(ops.generate_mask(dev(g["flags"])).cpu().numpy(), g["mask"])
+
+
+def test_flip_golden(ops):
+    g = load("g2_flip.npz")
+    A0, flags = dev(g["A0"]), dev(g["flags"])
+    for k in range(4):
+        a_t, tgt = ops.edgeflip(A0, flags, float(g[f"batched_{k}_sigma"]), U=dev(g[f"batched_{k}_U"]))
+        assert np.array_equal(a_t.cpu().numpy(), g[f"batched_{k}_At"])
+        assert np.array_equal(tgt.cpu().numpy(), g[f"batched_{k}_target"])
+    a_t, tgt = ops.edgeflip(A0, flags, g["single_sigmas"], U=dev(g["single_U"]))
+    assert np.array_equal(a_t.cpu().numpy(), g["single_At"])
+    assert np.array_equal(tgt.cpu().numpy(), g["single_target"])
+
+
+def _replay_chain(ops, g, kind, use_probs):
+    """Replays the reference chain with the recorded logits in place of the model.  With use_probs the kernels get the
+    reference's own post-sigmoid probabilities (bit-exact contract); otherwise they apply their own sigmoid."""
+    from oracle import diffusion as od
+    T, flags, U = int(g["T"]), dev(g["flags"]), g["U"]
+    x = ops.init_xT(flags, U=dev(U[0]))
+    mism = 0
+    if kind == "simple":
+        sig = od.schedule_simple(T)
+        for c in range(T):
+            s = sig[len(sig) - c - 1]
+            a_t, _ = ops.edgeflip(x, flags, s, U=dev(U[1 + 2 * c]), want_target=False)
+            assert np.array_equal(a_t.cpu().numpy(), g["model_A"][c]), f"A_t differs at step {c}"
+            lg = g["model_logits"][c]
+            inp = dev(torch.sigmoid(torch.from_numpy(lg)).numpy()) if use_probs else dev(lg)
+            x = ops.reverse_step_simple(a_t, inp, flags, U=dev(U[2 + 2 * c]), is_probs=use_probs)
+    else:
+        for c, (st, beta, st1) in enumerate(od.schedule_vlb(T)):
+            if use_probs:
+                assert np.array_equal(x.cpu().numpy(), g["model_A"][c]), f"A_t differs at step {c}"
+            else:
+                mism += int((x.cpu().numpy() != g["model_A"][c]).sum())
+                x = dev(g["model_A"][c])     # re-synchronise so one ulp of sigmoid cannot cascade
+            lg = g["model_logits"][c]
+            inp = dev(torch.sigmoid(torch.from_numpy(lg)).numpy()) if use_probs else dev(lg)
+            x = ops.reverse_step_vlb(x, inp, flags, st, beta, st1, U=dev(U[1 + c]), is_probs=use_probs)
+    return x.cpu().numpy(), mism
+
+
+@pytest.mark.parametrize("kind", ["simple", "vlb"])
+def test_chain_golden_bit_exact_from_probs(ops, kind):
+    g = load(f"g4_chain_{kind}.npz")
+    final, _ = _replay_chain(ops, g, kind, use_probs=True)
+    assert np.array_equal(final, g["final"])
+
+
+@pytest.mark.parametrize("kind", ["simple", "vlb"])
+def test_chain_golden_from_logits(ops, kind):
+    """Device sigmoid (ocml expf) vs torch-CPU sigmoid may differ in the last ulp; a Bernoulli outcome changes only if
+    u falls inside that ulp.  Allow at most 2 differing entries over the whole chain (expected: 0)."""
+    g = load(f"g4_chain_{kind}.npz")
+    final, mism = _replay_chain(ops, g, kind, use_probs=False)
+    if kind == "vlb":
+        assert mism + int((final != g["final"]).sum()) <= 2
+    else:
+        assert int((final != g["final"]).sum()) <= 2 * 16
+
+
+# ------------------------------------------------------------------ oracle on seeded inputs, ragged sizes
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 31), (2, 32), (3, 33), (4, 64), (2, 97), (2, 200)])
+def test_flip_init_reverse_vs_oracle(ops, B, N):
+    from oracle import diffusion as od
+    rng = np.random.default_rng(1000 + N)
+    A0, flags = rand_graphs(rng, B, N)
+    if N == 1:
+        flags[:] = 1
+    U = rng.random((4, B, N, N), dtype=np.float32)
+    sig = rng.uniform(0, 0.5, size=B)
+    a_t, tgt = ops.edgeflip(dev(A0), dev(flags), sig, U=dev(U[0]))
+    ra, rt = od.discretenoise(A0, flags, sig, U[0])
+    assert np.array_equal(a_t.cpu().numpy(), ra.numpy()) and np.array_equal(tgt.cpu().numpy(), rt.numpy())
+    assert np.array_equal(ops.init_xT(dev(flags), U=dev(U[1])).cpu().numpy(), od.gen_init_data(flags, U[1]).numpy())
+    probs = rng.random((B, N, N), dtype=np.float32)
+    out = ops.reverse_step_simple(a_t, dev(probs), dev(flags), U=dev(U[2]), is_probs=True)
+    assert np.array_equal(out.cpu().numpy(), od.reverse_step_simple(ra, probs, flags, U[2]).numpy())
+    st, beta, st1 = 0.3125, 0.0625 / (1 - 2 * 0.25), 0.25
+    out = ops.reverse_step_vlb(a_t, dev(probs), dev(flags), st, beta, st1, U=dev(U[3]), is_probs=True)
+    ref = od.reverse_step_vlb(ra, probs, flags, od.vlb_scalars(st, beta, st1), U[3])
+    assert np.array_equal(out.cpu().numpy(), ref.numpy())
+
+
+def test_flip_in_place_and_properties(ops):
+    rng = np.random.default_rng(5)
+    A0, flags = rand_graphs(rng, 4, 50)
+    a = dev(A0)
+    same, _ = ops.edgeflip(a, dev(flags), 0.0, seed=9, want_target=False)       # sigma = 0 -> identity
+    assert torch.equal(same, a)
+    half, tgt = ops.edgeflip(a, dev(flags), 0.5, seed=9)
+    assert torch.equal(half, half.transpose(1, 2)) and float(half.diagonal(dim1=1, dim2=2).abs().sum()) == 0
+    assert torch.equal(tgt, (half - a).abs() * dev(flags)[:, :, None] * dev(flags)[:, None, :])
+    inplace = a.clone()
+    ops.edgeflip(inplace, dev(flags), 0.5, seed=9, want_target=False, out=inplace)
+    assert torch.equal(inplace, half)
+
+
+def test_philox_matches_oracle_and_is_batch_independent(ops):
+    from oracle import diffusion as od, philox
+    rng = np.random.default_rng(6)
+    A0, flags = rand_graphs(rng, 5, 40)
+    seed, off = 0x1234ABCD5678, 7
+    a_t, _ = ops.edgeflip(dev(A0), dev(flags), 0.25, seed=seed, graph_id0=10, offset=off, want_target=False)
+    U = philox.uniform_pairs(seed, np.arange(10, 15), off, 40)
+    ref, _ = od.discretenoise(A0, flags, 0.25, U)
+    assert np.array_equal(a_t.cpu().numpy(), ref.numpy())
+    # the same graphs processed as a different shard give the same bits
+    part, _ = ops.edgeflip(dev(A0[2:]), dev(flags[2:]), 0.25, seed=seed, graph_id0=12, offset=off, want_target=False)
+    assert torch.equal(part, a_t[2:])
+
+
+def test_full_size_properties_n200(ops):
+    """BASELINE size (N=200, B=32): structural properties that do not need the oracle."""
+    rng = np.random.default_rng(7)
+    A0, flags = rand_graphs(rng, 32, 200)
+    a, f = dev(A0), dev(flags)
+    x = ops.init_xT(f, seed=3)
+    assert torch.equal(x, x.transpose(1, 2))
+    m = ops.generate_mask(f)
+    assert float((x * (1 - m)).abs().sum()) == 0
+    dens = float(x.sum() / m.sum())
+    assert 0.45 < dens < 0.55
+    logits = torch.randn(32, 200, 200, device="cuda")
+    y = ops.reverse_step_vlb(x, logits, f, 0.5, 0.5 / 64, 0.5 - 0.5 / 64, seed=3, offset=1)
+    assert torch.equal(y, y.transpose(1, 2)) and float((y * (1 - m)).abs().sum()) == 0
+    assert set(np.unique(y.cpu().numpy()).tolist()) <= {0.0, 1.0}
+    z = ops.reverse_step_simple(x, logits, f, seed=3, offset=2)
+    assert torch.equal(z, z.transpose(1, 2)) and set(np.unique(z.cpu().numpy()).tolist()) <= {0.0, 1.0}
+
+
+# ------------------------------------------------------------------ losses
+def test_losses_golden(ops):
+    from oracle import diffusion as od
+    g = load("g3_losses.npz")
+    loss, ds = ops.loss_bce(dev(g["bce_score"]), dev(g["bce_target"]), g["bce_sigmas"], dev(g["mask"]))
+    np.testing.assert_allclose(loss.item(), float(g["bce_loss"]), rtol=1e-5)          # north-star bound: 1e-3
+    np.testing.assert_allclose(ds.cpu().numpy(), g["bce_dscore"], rtol=1e-4, atol=1e-8)
+    st = g["vlb_sigma_list"]
+    sched = np.stack([st, g["vlb_nontild"], st - st / g["vlb_ind"]], 1)
+    loss, ds = ops.loss_vlb(dev(g["vlb_score"]), dev(g["vlb_At"]), dev(g["A0"]), sched, dev(g["mask"]))
+    np.testing.assert_allclose(loss.item(), float(g["vlb_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(ds.cpu().numpy(), g["vlb_dscore"], rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N", [(1, 3), (5, 33), (8, 100)])
+def test_losses_vs_oracle(ops, B, N):
+    from oracle import diffusion as od
+    rng = np.random.default_rng(40 + N)
+    A0, flags = rand_graphs(rng, B, N)
+    mask = od.generate_mask(flags).numpy()
+    sig = rng.uniform(0, 0.5, size=B)
+    a_t, tgt = od.discretenoise(A0, flags, sig, rng.random((B, N, N), dtype=np.float32))
+    score = rng.normal(0, 2, size=(B, N, N)).astype(np.float32)
+    s = torch.from_numpy(score).requires_grad_(True)
+    ref = od.loss_bce(s, tgt, sig, mask)
+    ref.backward()
+    loss, ds = ops.loss_bce(dev(score), dev(tgt.numpy()), sig, dev(mask))
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(ds.cpu().numpy(), s.grad.numpy(), rtol=1e-4, atol=1e-9)
+    T = 16
+    t = rng.integers(1, T + 1, size=B)
+    line = torch.linspace(0, 0.5, T + 1).tolist()
+    beta = od.sigma_lin(line)
+    st = np.asarray([line[i] for i in t])
+    bt = np.asarray([beta[i] for i in t])
+    a_t, _ = od.discretenoise(A0, flags, st, rng.random((B, N, N), dtype=np.float32))
+    s = torch.from_numpy(score).requires_grad_(True)
+    ref = od.loss_vlb(s, a_t, A0, od.vlb_train_scalars(st, t, bt), mask)
+    ref.backward()
+    loss, ds = ops.loss_vlb(dev(score), dev(a_t.numpy()), dev(A0), np.stack([st, bt, st - st / t], 1), dev(mask))
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    np.testing.assert_allclose(ds.cpu().numpy(), s.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+def test_bad_arguments_raise(ops):
+    f = torch.ones(2, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.edgeflip(torch.zeros(2, 4, 4), f, 0.1)                       # CPU tensor
+    with pytest.raises(ValueError):
+        ops.edgeflip(torch.zeros(2, 4, 4, device="cuda"), f[:, :3].contiguous(), 0.1)
+    with pytest.raises(RuntimeError):
+        ops.edgeflip(torch.zeros(2, 4, 4, device="cuda"), f, 1.5)        # sigma outside [0,1] -> ABI status
