@@ -33,6 +33,7 @@ struct GemmArgs {
   GemmSeg seg[2];
   int nseg;
   int M, N;
+  int n_store;             // columns written per row (>= N; columns in [N, n_store) get zeros), 0 = N
   int a_vec, b_vec;        // 16-byte vector loads allowed (base, ld and offsets 16-byte aligned)
   int nsplit, kchunk;      // split-K over segment 0 (nsplit > 1): blockIdx.z = g * nsplit + split
   float* C; long c_bs; int ldc;
@@ -133,11 +134,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (ACfg::LDS_FLOATS + BCfg::LDS_FLOATS)];
   constexpr int STAGE_FLOATS = ACfg::LDS_FLOATS + BCfg::LDS_FLOATS;   // stage s: A slab at s*STAGE, B slab behind it
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: tile_ok branches stay scalar
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int z = blockIdx.z;
   const int g = z / p.nsplit, split = z % p.nsplit;
+
+  const int nstore = p.n_store > p.N ? p.n_store : p.N;
 
   floatx16 acc[FM][FN];
 #pragma unroll
@@ -147,11 +151,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  bool tile_ok[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) tile_ok[i][j] = (m0 + wm * TM + i * 32 < p.M) && (n0 + wn * TN + j * 32 < p.N);
+  // The MFMA chain is kept free of branches (a conditional MFMA makes hipcc shuttle the accumulators through VGPRs
+  // around every instruction); waves whose tile lies outside the output multiply zero-filled slabs and skip the store.
+  const bool wave_ok = (m0 + wm * TM < p.M) && (n0 + wn * TN < nstore);
 
   float rs[ACfg::PER_THREAD];
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          if (tile_ok[i][j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
       if (p.rowsum && !A_KMAJOR) {
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      if (!tile_ok[i][j]) continue;
+      if (!wave_ok) continue;
       const int n = n0 + wn * TN + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -254,6 +256,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
           if (dact) v *= dact[off] > 0.f ? 1.f : kSlope;
           if (p.accumulate) v += C[off];
           C[off] = v;
+        } else if (m < p.M && n < nstore) {
+          C[(size_t)m * p.ldc + n] = 0.f;
         }
       }
     }
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 
 template <int BM, int BN, int WM, int WN>
 inline int launch_gemm_cfg(const GemmArgs& a, int batch_z, bool a_kmajor, bool b_kmajor, hipStream_t st) {
-  dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), batch_z), block(256);
+  dim3 grid(cdiv(a.n_store > a.N ? a.n_store : a.N, BN), cdiv(a.M, BM), batch_z), block(256);
   if (!a_kmajor && b_kmajor) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, a);
   else if (a_kmajor && b_kmajor) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, a);
   else if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, a);

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __
   }
 }
 
-// dy = rstd * m * (g - mean_m(g) - u * mean_m(g*u))   (u already carries the mask)
+// dy = rstd * m * (g - mean_m(g) - (u - mean_m(u)) * mean_m(g*u))   (u already carries the mask).
+// mean_m(u) is zero in exact arithmetic; keeping it makes sum(dy) vanish structurally, as it does in the autograd
+// graph of util/model_helper.py:182-190 (the rounding of the forward mean otherwise leaks a constant into dy).
 __global__ __launch_bounds__(NORM_THREADS) void inorm_bwd_kernel(const float* __restrict__ g, long g_bs,
                                                                  const float* __restrict__ u, long u_bs,
                                                                  const float* __restrict__ maskp,
@@ -201,22 +203,24 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_bwd_kernel(const float* __
   const float4* mp = reinterpret_cast<const float4*>(maskp + (size_t)b * P);
   float4* dp = reinterpret_cast<float4*>(dy + ((size_t)b * C + c) * P);
   const int P4 = P / 4;
-  float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f, cnt = 0.f;
   for (int idx = threadIdx.x; idx < P4; idx += NORM_THREADS) {
     const float4 a = gp[idx], x = up[idx], m = mp[idx];
     s1 += a.x * m.x + a.y * m.y + a.z * m.z + a.w * m.w;
     s2 += a.x * x.x + a.y * x.y + a.z * x.z + a.w * x.w;
+    s3 += (x.x + x.y) + (x.z + x.w);
     cnt += m.x + m.y + m.z + m.w;
   }
   s1 = block_sum_1024(s1, sh);
   s2 = block_sum_1024(s2, sh);
+  s3 = block_sum_1024(s3, sh);
   cnt = block_sum_1024(cnt, sh);
   const float rstd = rstd_in[blockIdx.x];
-  const float m1 = s1 / cnt, m2 = s2 / cnt;
+  const float m1 = s1 / cnt, m2 = s2 / cnt, ubar = s3 / cnt;
   for (int idx = threadIdx.x; idx < P4; idx += NORM_THREADS) {
     const float4 a = gp[idx], x = up[idx], m = mp[idx];
-    dp[idx] = make_float4(rstd * m.x * (a.x - m1 - x.x * m2), rstd * m.y * (a.y - m1 - x.y * m2),
-                          rstd * m.z * (a.z - m1 - x.z * m2), rstd * m.w * (a.w - m1 - x.w * m2));
+    dp[idx] = make_float4(rstd * m.x * (a.x - m1 - (x.x - ubar) * m2), rstd * m.y * (a.y - m1 - (x.y - ubar) * m2),
+                          rstd * m.z * (a.z - m1 - (x.z - ubar) * m2), rstd * m.w * (a.w - m1 - (x.w - ubar) * m2));
   }
 }
 
@@ -289,6 +293,8 @@ struct Ctx {
   float* at(size_t off) const { return ws + off; }
 };
 
+struct Geo { int B, P; hipStream_t st; };
+
 GemmArgs base_args() {
   GemmArgs a{};
   a.nseg = 1; a.nsplit = 1; a.kchunk = 0; a.scale_div = 1; a.mul_div = 1;
@@ -300,7 +306,13 @@ struct LinArgs {
   const float* W; int ldw; bool w_trans;   // w_trans: use W^T (W is stored [K][M] with pitch ldw)
   const float* X; long x_bs; int K;
 };
+int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const float* bias, int act, const float* mulmask,
+           const float* dact, long dact_bs, float* Y, long y_bs, bool accumulate);
 int linear(const Ctx& c, int M, const LinArgs& s0, const LinArgs* s1, const float* bias, int act, const float* mulmask,
+           const float* dact, long dact_bs, float* Y, long y_bs, bool accumulate) {
+  return linear(Geo{c.w.B, c.w.P, c.st}, M, s0, s1, bias, act, mulmask, dact, dact_bs, Y, y_bs, accumulate);
+}
+int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const float* bias, int act, const float* mulmask,
            const float* dact, long dact_bs, float* Y, long y_bs, bool accumulate) {
   GemmArgs a = base_args();
   const LinArgs* segs[2] = {&s0, s1};
@@ -308,44 +320,48 @@ int linear(const Ctx& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
   a.a_vec = 1;
   for (int i = 0; i < a.nseg; ++i) {
     a.seg[i].A = segs[i]->W; a.seg[i].a_bs = 0; a.seg[i].lda = segs[i]->ldw;
-    a.seg[i].B = segs[i]->X; a.seg[i].b_bs = segs[i]->x_bs; a.seg[i].ldb = c.w.P;
+    a.seg[i].B = segs[i]->X; a.seg[i].b_bs = segs[i]->x_bs; a.seg[i].ldb = c.P;
     a.seg[i].K = segs[i]->K;
     if (segs[i]->w_trans != s0.w_trans) return fail(DPPM_E_INVALID, "linear: segments must share the weight orientation");
     if (!aligned16(segs[i]->W) || segs[i]->ldw % 4 != 0) a.a_vec = 0;
   }
   a.b_vec = 1;   // planes are 16-byte aligned by construction (P % 4 == 0, workspace 256-byte aligned)
-  a.M = M; a.N = c.w.P;
-  a.C = Y; a.c_bs = y_bs; a.ldc = c.w.P;
+  a.M = M; a.N = c.P;
+  a.C = Y; a.c_bs = y_bs; a.ldc = c.P;
   a.bias = bias; a.act = act;
-  a.mul = mulmask; a.mul_bs = c.w.P; a.mul_ld = 0; a.mul_div = 1;
+  a.mul = mulmask; a.mul_bs = c.P; a.mul_ld = 0; a.mul_div = 1;
   a.dact = dact; a.dact_bs = dact_bs;
   a.accumulate = accumulate ? 1 : 0;
-  return launch_gemm(a, c.w.B, /*a_kmajor=*/s0.w_trans, /*b_kmajor=*/true, c.st);
+  return launch_gemm(a, c.B, /*a_kmajor=*/s0.w_trans, /*b_kmajor=*/true, c.st);
 }
 
 // dW (M x Nw, pitch ldo) = sum_b dY[b] (M x P) * X[b]^T (P x Nw) ; optional db = row sums of dY
-int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
-  const Layout& w = c.w;
-  const int nsplit = wgrad_nsplit(w.B, w.P), kchunk = wgrad_kchunk(w.B, w.P);
-  const int nz = w.B * nsplit;
-  if ((size_t)nz * M * Nw > w.slab_floats) return fail(DPPM_E_INVALID, "wgrad: slab buffer too small");
+int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo,
+              float* db, float* slabs, size_t slab_floats, float* rsum) {
+  const int nsplit = wgrad_nsplit(c.B, c.P), kchunk = wgrad_kchunk(c.B, c.P);
+  const int nz = c.B * nsplit;
+  if ((size_t)nz * M * Nw > slab_floats) return fail(DPPM_E_INVALID, "wgrad: slab buffer too small");
   GemmArgs a = base_args();
-  a.seg[0].A = dY; a.seg[0].a_bs = dy_bs; a.seg[0].lda = w.P;
-  a.seg[0].B = X; a.seg[0].b_bs = x_bs; a.seg[0].ldb = w.P;
-  a.seg[0].K = w.P;
-  a.a_vec = 1; a.b_vec = 1;
+  a.seg[0].A = dY; a.seg[0].a_bs = dy_bs; a.seg[0].lda = c.P;
+  a.seg[0].B = X; a.seg[0].b_bs = x_bs; a.seg[0].ldb = c.P;
+  a.seg[0].K = c.P;
+  a.a_vec = aligned16(dY) && dy_bs % 4 == 0 && c.P % 4 == 0;
+  a.b_vec = aligned16(X) && x_bs % 4 == 0 && c.P % 4 == 0;
   a.nsplit = nsplit; a.kchunk = kchunk;
   a.M = M; a.N = Nw;
-  a.C = c.at(w.slabs); a.c_bs = (long)M * Nw; a.ldc = Nw;
-  a.rowsum = db ? c.at(w.rsum) : nullptr;
+  a.C = slabs; a.c_bs = (long)M * Nw; a.ldc = Nw;
+  a.rowsum = db ? rsum : nullptr;
   DPPM_TRY(launch_gemm(a, nz, false, false, c.st));
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, 256)), dim3(256), 0, c.st, c.at(w.slabs), nz, M, Nw, dW, ldo);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, 256)), dim3(256), 0, c.st, slabs, nz, M, Nw, dW, ldo);
   DPPM_TRY(check_launch("reduce_slabs(dW)"));
   if (db) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(M, 256)), dim3(256), 0, c.st, c.at(w.rsum), nz, 1, M, db, M);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(M, 256)), dim3(256), 0, c.st, rsum, nz, 1, M, db, M);
     DPPM_TRY(check_launch("reduce_slabs(db)"));
   }
   return DPPM_OK;
+}
+int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
+  return wgrad_raw(Geo{c.w.B, c.w.P, c.st}, M, dY, dy_bs, Nw, X, x_bs, dW, ldo, db, c.at(c.w.slabs), c.w.slab_floats, c.at(c.w.rsum));
 }
 
 // per-plane products for all (b,c): C = op(A) * op(B) * inv_norm[b] (* mask[b])
@@ -357,7 +373,7 @@ int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batc
   a.seg[0].B = Bm; a.seg[0].b_bs = P; a.seg[0].ldb = ld;
   a.seg[0].K = n;
   a.a_vec = aligned16(A); a.b_vec = aligned16(Bm);
-  a.M = n; a.N = n;
+  a.M = n; a.N = n; a.n_store = ld;   // pad columns of the output plane are zeroed
   a.C = C; a.c_bs = P; a.ldc = ld;
   a.scale = scale; a.scale_div = div;
   a.mul = mask; a.mul_bs = P; a.mul_ld = ld; a.mul_div = div;
@@ -398,6 +414,32 @@ extern "C" int dppm_plane_matmul(const float* A, const float* Bm, float* C, int 
   DPPM_REQUIRE(!(trans_a && trans_b), "dppm_plane_matmul: A^T * B^T is not provided");
   DPPM_REQUIRE(scale_div >= 1, "dppm_plane_matmul: scale_div=%d", scale_div);
   return plane_mm(as_stream(stream), A, Bm, C, batch, n, ld, trans_a != 0, trans_b != 0, scale, mask, scale_div);
+}
+
+extern "C" int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float* X, long x_bs, int K, const float* bias, int act,
+                               const float* maskp, float* Y, long y_bs, int M, int B, int P, int accumulate, void* stream) {
+  DPPM_REQUIRE(W && X && Y, "dppm_linear_fwd: null pointer");
+  DPPM_REQUIRE(M > 0 && K > 0 && B > 0 && P > 0 && P % 4 == 0, "dppm_linear_fwd: M=%d K=%d B=%d P=%d (P must be a multiple of 4)", M, K, B, P);
+  DPPM_REQUIRE(ldw >= (trans_w ? M : K), "dppm_linear_fwd: ldw=%d too small", ldw);
+  DPPM_REQUIRE(aligned16(X) && aligned16(Y) && x_bs % 4 == 0 && y_bs % 4 == 0, "dppm_linear_fwd: planes must be 16-byte aligned");
+  return linear(Geo{B, P, as_stream(stream)}, M, LinArgs{W, ldw, trans_w != 0, X, x_bs, K}, nullptr, bias, act ? 1 : 0, maskp, nullptr, 0,
+                Y, y_bs, accumulate != 0);
+}
+
+extern "C" size_t dppm_linear_wgrad_workspace_bytes(int M, int Nw, int B, int P) {
+  if (M <= 0 || Nw <= 0 || B <= 0 || P <= 0) return 0;
+  const size_t nz = (size_t)B * wgrad_nsplit(B, P);
+  return (nz * M * Nw + nz * M + 64) * sizeof(float);
+}
+
+extern "C" int dppm_linear_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int M, int Nw, int B, int P, float* dW,
+                                 int ldo, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  DPPM_REQUIRE(dY && X && dW && workspace, "dppm_linear_wgrad: null pointer");
+  DPPM_REQUIRE(M > 0 && Nw > 0 && B > 0 && P > 0 && ldo >= Nw, "dppm_linear_wgrad: M=%d Nw=%d B=%d P=%d ldo=%d", M, Nw, B, P, ldo);
+  DPPM_REQUIRE(workspace_bytes >= dppm_linear_wgrad_workspace_bytes(M, Nw, B, P), "dppm_linear_wgrad: workspace too small");
+  const size_t nz = (size_t)B * wgrad_nsplit(B, P);
+  float* slabs = static_cast<float*>(workspace);
+  return wgrad_raw(Geo{B, P, as_stream(stream)}, M, dY, dy_bs, Nw, X, x_bs, dW, ldo, db, slabs, nz * M * Nw, slabs + nz * M * Nw);
 }
 
 extern "C" int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, float* u, long u_bs, int B, int C, int P,

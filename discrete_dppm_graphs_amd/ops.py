@@ -241,10 +241,43 @@ def plane_matmul(A, Bm, n, trans_a=False, trans_b=False, scale=None, mask=None, 
     if n_ != n:
         raise ValueError("plane_matmul: A must be [batch, n, ld]")
     Bm = _chk(Bm, "Bm", (batch, n, ld))
-    out = torch.zeros_like(A)
+    out = torch.empty_like(A)
     check(lib.dppm_plane_matmul(_ptr(A), _ptr(Bm), _ptr(out), batch, n, ld, int(trans_a), int(trans_b), _ptr(scale), _ptr(mask),
                                 int(scale_div), _stream()), "dppm_plane_matmul")
     return out
+
+
+def linear_fwd(W, X, bias=None, act=False, maskp=None, trans_w=False, out=None, accumulate=False):
+    """X: [B, K, P] planes; W: [M, K] (or [K, M] with trans_w) -> Y [B, M, P]."""
+    X = _chk(X, "X")
+    B, K, P = X.shape
+    if W.dim() != 2 or not W.is_cuda or W.dtype != torch.float32 or W.stride(1) != 1:
+        raise ValueError("W: expected a 2-d float32 cuda tensor with unit column stride")
+    M = W.shape[1] if trans_w else W.shape[0]
+    if (W.shape[0] if trans_w else W.shape[1]) != K:
+        raise ValueError(f"W: shape {tuple(W.shape)} does not match K={K}")
+    Y = out if out is not None else torch.empty(B, M, P, device=X.device, dtype=torch.float32)
+    _chk(Y, "out", (B, M, P))
+    check(lib.dppm_linear_fwd(_ptr(W), int(W.stride(0)), int(trans_w), _ptr(X), C.c_long(K * P), K, _ptr(bias), int(act),
+                              _ptr(maskp), _ptr(Y), C.c_long(M * P), M, B, P, int(accumulate), _stream()), "dppm_linear_fwd")
+    return Y
+
+
+def linear_wgrad(dY, X, want_bias=True):
+    """dY: [B, M, P], X: [B, Nw, P] -> (dW [M, Nw], db [M] or None)."""
+    dY = _chk(dY, "dY")
+    B, M, P = dY.shape
+    X = _chk(X, "X")
+    Nw = X.shape[1]
+    if X.shape[0] != B or X.shape[2] != P:
+        raise ValueError("X: batch / plane size mismatch")
+    nbytes = lib.dppm_linear_wgrad_workspace_bytes(M, Nw, B, P)
+    ws = torch.empty((nbytes + 3) // 4, device=dY.device, dtype=torch.float32)
+    dW = torch.empty(M, Nw, device=dY.device, dtype=torch.float32)
+    db = torch.empty(M, device=dY.device, dtype=torch.float32) if want_bias else None
+    check(lib.dppm_linear_wgrad(_ptr(dY), C.c_long(M * P), _ptr(X), C.c_long(Nw * P), M, Nw, B, P, _ptr(dW), Nw, _ptr(db), _ptr(ws),
+                                C.c_size_t(nbytes), _stream()), "dppm_linear_wgrad")
+    return dW, db
 
 
 def inorm_fwd(y, maskp):

@@ -162,6 +162,21 @@ int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int 
 int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, float* u, long u_bs, int B, int C, int P,
                    float* mean_out, float* rstd_out, void* stream);
 
+/* Y[b] (M x P) = epilogue(W (M x K) * X[b] (K x P)): one nn.Linear of the reference applied at every (i,j), in
+ * channel-first planes (model/ppgn.py:58-59,69,301,327,331).  W is torch's [out][in] weight with row pitch ldw;
+ * trans_w != 0 applies W^T instead (W is then [K][M]: the data-gradient form).  bias (nullable) [M]; act != 0 applies
+ * LeakyReLU(0.01); maskp (nullable) [B][P] multiplies the result; accumulate != 0 adds into Y.
+ * x_bs / y_bs: floats between consecutive graphs. */
+int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float* X, long x_bs, int K, const float* bias, int act,
+                    const float* maskp, float* Y, long y_bs, int M, int B, int P, int accumulate, void* stream);
+
+/* dW (M x Nw, row pitch ldo) = sum_b dY[b] (M x P) * X[b]^T (P x Nw), db (nullable) [M] = sum_{b,p} dY[b][m][p]:
+ * the weight/bias gradient of the Linear above (split-K partial slabs + ordered reduction, bitwise reproducible).
+ * workspace: dppm_linear_wgrad_workspace_bytes(M, Nw, B, P). */
+size_t dppm_linear_wgrad_workspace_bytes(int M, int Nw, int B, int P);
+int dppm_linear_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int M, int Nw, int B, int P, float* dW,
+                      int ldo, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser
  * ---------------------------------------------------------------------------------------------- */

@@ -28,7 +28,7 @@ def dev(x, dtype=torch.float32):
 def rand_graphs(rng, B, N, ragged=True):
     A = np.zeros((B, N, N), np.float32)
     for b in range(B):
-        n = int(rng.integers(max(2, N // 2), N + 1)) if ragged else N
+        n = int(rng.integers(min(N, max(2, N // 2)), N + 1)) if ragged else N
         up = np.triu((rng.random((n, n)) < 0.3).astype(np.float32), 1)
         for i in range(n - 1):
             up[i, i + 1] = 1

@@ -46,6 +46,7 @@ def run_gpu(ops, W, A, mask, sigma, L, H, dlogits=None):
     pack = ops.ParamPack(tensors, L, H)
     B, N, _ = A.shape
     ws = ops.ppgn_workspace(B, N, H, L, dlogits is not None, "cuda")
+    ws.fill_(float("nan"))     # any read of an element no kernel wrote poisons the result
     sig = dev(np.broadcast_to(np.asarray(sigma, np.float64).astype(np.float32), (B,)).copy())
     logits = ops.ppgn_forward(pack, dev(A), dev(mask), sig, ws, training=dlogits is not None)
     grads = None
@@ -104,7 +105,7 @@ def test_inference_equals_training_forward(ops):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("n", [5, 32, 33, 100, 200])
+@pytest.mark.parametrize("n", [5, 32, 33, 40, 64, 100, 200])
 def test_plane_matmul_variants(ops, n):
     rng = np.random.default_rng(n)
     ld = (n + 3) // 4 * 4
@@ -120,6 +121,31 @@ def test_plane_matmul_variants(ops, n):
         ref = ref * np.repeat(scale, 2)[:, None, None]
         close(out[:, :, :n], ref, tol=1e-5)
         assert np.all(out[:, :, n:] == 0)
+
+
+@pytest.mark.parametrize("M,K,P,B", [(8, 8, 48, 2), (34, 16, 1188, 3), (64, 64, 64, 2), (40, 64, 400, 1), (128, 128, 3600, 2),
+                                     (194, 64, 64, 2), (66, 32, 400, 2), (32, 2, 400, 2), (130, 20, 132, 1)])
+def test_linear_fwd_and_wgrad_blocks(ops, M, K, P, B):
+    """Every tile configuration x operand orientation of the GEMM family, against float64 numpy."""
+    rng = np.random.default_rng(M * 7 + K)
+    X = rng.normal(size=(B, K, P)).astype(np.float32)
+    W = rng.normal(size=(M, K)).astype(np.float32)
+    bias = rng.normal(size=M).astype(np.float32)
+    maskp = (rng.random((B, P)) < 0.7).astype(np.float32)
+    ref = np.einsum("mk,bkp->bmp", W.astype(np.float64), X.astype(np.float64)) + bias[None, :, None]
+    ref = np.where(ref > 0, ref, 0.01 * ref) * maskp[:, None, :]
+    Y = ops.linear_fwd(dev(W), dev(X), bias=dev(bias), act=True, maskp=dev(maskp))
+    close(Y.cpu().numpy(), ref, tol=1e-5)
+    # transposed weight + accumulate (the data-gradient form): Z = Z0 + W^T Y
+    Z0 = rng.normal(size=(B, K, P)).astype(np.float32)
+    Yn = Y.cpu().numpy().astype(np.float64)
+    refz = Z0 + np.einsum("mk,bmp->bkp", W.astype(np.float64), Yn)
+    Z = ops.linear_fwd(dev(W), Y, trans_w=True, out=dev(Z0), accumulate=True)
+    close(Z.cpu().numpy(), refz, tol=1e-5)
+    # weight / bias gradient
+    dW, db = ops.linear_wgrad(Y, dev(X))
+    close(dW.cpu().numpy(), np.einsum("bmp,bkp->mk", Yn, X.astype(np.float64)), tol=2e-5)
+    close(db.cpu().numpy(), Yn.sum(axis=(0, 2)), tol=2e-5)
 
 
 def test_inorm_vs_oracle(ops):
