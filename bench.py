@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the discrete graph-DDPM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on): synthetic SBM graphs with N = 200 nodes,
+the 8 x 128 PPGN of gridsearch_ppgn_simple.py:19, `ppgn_simple` sampling with 64 noise levels, 32 graphs per GPU.
+One step = one full reverse chain (x_T init, then 64 x [re-noise, denoiser forward, reverse step]) over one batch; graphs
+are independent, so ranks take disjoint graph ids and exchange nothing (weak scaling).  `value` = graphs finished per
+second over all ranks.  The same line also carries the training throughput (optimizer steps/s at global batch
+32 x N GPUs, data parallel with one flat-gradient all-reduce per step), the roofline of the dominant kernel measured
+live with HIP events, and a CPU baseline (the oracle's torch-CPU restatement on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def sbm_graphs(rng, B, N, p_intra=0.3, p_inter=0.005):
+    """k = ceil(N/25) blocks, all nodes active, symmetric, zero diagonal."""
+    k = -(-N // 25)
+    A = np.zeros((B, N, N), np.float32)
+    for b in range(B):
+        blocks = rng.integers(0, k, size=N)
+        same = blocks[:, None] == blocks[None, :]
+        up = np.triu(rng.random((N, N)) < np.where(same, p_intra, p_inter), 1).astype(np.float32)
+        for i in range(N - 1):      # keep every node at degree >= 1 so flags = adj.sum(-1) > 0 marks all N active
+            up[i, i + 1] = 1.0
+        A[b] = up + up.T
+    return A
+
+
+def fwd_flops_per_graph(N, H, L):
+    """SURVEY.md section 8(d)."""
+    return 4 * N * N * H + L * (12 * N * N * H * H + 2 * H * N ** 3) + 2 * N * N * H * (L * H + 2) + 2 * N * N * H * H + 2 * N * N * H
+
+
+def cpu_baseline(N, H, L, T, seconds_budget=20.0):
+    """The oracle (oracle/ppgn.py + oracle/diffusion.py, torch CPU fp32) on a bounded sample of the same workload:
+    2 graphs through as many chain steps as fit the budget (>= 2), extrapolated to the full T-step chain."""
+    from oracle import diffusion as od, ppgn as op
+    rng = np.random.default_rng(1234)
+    Bc = 2
+    A = sbm_graphs(rng, Bc, N)
+    flags = (A.sum(-1) > 1e-5).astype(np.float32)
+    mask = od.generate_mask(flags)
+    W = op.init_weights(L, H, seed=1234)
+    x = od.gen_init_data(flags, rng.random((Bc, N, N), dtype=np.float32))
+    sig = od.schedule_simple(T)
+    steps, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while steps < 2 or (time.perf_counter() - t0 < seconds_budget and steps < T):
+            s = sig[len(sig) - steps - 1]
+            x, _ = od.take_step_simple(x, lambda a: op.powerful_forward(W, a, mask, s, L).squeeze(-1), flags, s,
+                                       rng.random((Bc, N, N), dtype=np.float32), rng.random((Bc, N, N), dtype=np.float32))
+            steps += 1
+    dt = time.perf_counter() - t0
+    per_graph_chain = dt / steps * T / Bc
+    return {"value": 1.0 / per_graph_chain, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{Bc} graphs x {steps} of {T} chain steps (N={N}, {L}x{H} PPGN, torch CPU fp32 oracle), extrapolated to the full chain"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nodes", type=int, default=200)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--levels", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=32, help="graphs per GPU")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed optimizer steps for the training figure (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from discrete_dppm_graphs_amd import engine, ops
+    from discrete_dppm_graphs_amd.model.ppgn import Powerful
+
+    N, H, L, T, B = args.nodes, args.hidden, args.layers, args.levels, args.batch
+    torch.manual_seed(1234)
+    model = Powerful(num_layers=L, hidden=H, hidden_final=H, n_nodes=N, normalization="instance", adj_out=True,
+                     input_features=2, dropout_p=1e-6).cuda().eval()
+    rng = np.random.default_rng(1234 + rank)
+    flags = torch.ones(B, N, device="cuda")
+    seed = 1234
+    gid0 = rank * B
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ sampling (headline)
+    for w in range(args.warmup):
+        engine.sample_chain_simple(model, flags, T, seed + w, gid0)
+    barrier()
+    ops.prof_begin()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = engine.sample_chain_simple(model, flags, T, seed + 100 + k, gid0 + k * world * B)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, truncated = ops.prof_end()
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert out.shape == (B, N, N) and torch.equal(out, out.transpose(1, 2))
+    graphs_per_s = args.steps * B * world / dt
+
+    # ------------------------------------------------------------------ training throughput (second half of the metric)
+    train = None
+    if args.train_steps > 0:
+        model.train()
+        state = engine.FlatState(model, lr=1e-3)
+        adj = torch.as_tensor(sbm_graphs(rng, B, N)).cuda()
+        sig = lambda: np.random.default_rng(99).uniform(0.0, 0.5, size=B)
+        loss = engine.train_step_simple(model, state, adj, sig(), seed, 0, gid0, B_global=B * world)
+        barrier()
+        ops.prof_begin()
+        t0 = time.perf_counter()
+        for k in range(args.train_steps):
+            loss = engine.train_step_simple(model, state, adj, sig(), seed, 1 + k, gid0, B_global=B * world)
+        barrier()
+        tdt = time.perf_counter() - t0
+        tprof, _ = ops.prof_end()
+        tm = torch.tensor([tdt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tdt = float(tm.item())
+        F = fwd_flops_per_graph(N, H, L)
+        train = {"train_steps_per_s": args.train_steps / tdt, "ms_per_train_step": 1e3 * tdt / args.train_steps,
+                 "global_batch": B * world, "loss": float(loss.item()),
+                 "model_tflops": 3 * F * B * world * args.train_steps / tdt / 1e12,
+                 "kernel_classes": {k: {"ms_per_step": v["ms"] / args.train_steps,
+                                        "tflops": (v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and k != "inorm" else None}
+                                    for k, v in tprof.items()}}
+        model.eval()
+
+    if rank == 0:
+        lin, pmm, nrm = prof["linear_gemm"], prof["plane_matmul"], prof["inorm"]
+        ach = lin["work"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
+        F = fwd_flops_per_graph(N, H, L)
+        line = {
+            "metric": "graphs sampled/s (PPGN, N=200); train steps/s in `train`", "value": graphs_per_s, "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ppgn_simple sampling on synthetic SBM N={N} (BASELINE configs[3]): {L}x{H} PPGN, "
+                                   f"{T} noise levels, {B} graphs/GPU per chain", "nodes": N, "hidden": H, "layers": L,
+                       "noise_levels": T, "graphs_per_gpu": B, "parallelism": f"graph-sharded x{world}, no collective"},
+            "model_tflops": graphs_per_s * T * F / 1e12,
+            "roofline": {"kernel": "gemm_f32_kernel<...,TAG=0> (per-position linear layers on v_mfma_f32_32x32x2_f32)",
+                         "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": lin["launches"], "avg_launch_ms": lin["ms"] / max(lin["launches"], 1),
+                         "share_of_step_time": lin["ms"] * 1e-3 / dt, "records_truncated": truncated},
+            "roofline_matmul": {"kernel": "gemm_f32_kernel<...,TAG=1> (per-channel N x N contraction, model/ppgn.py:62)",
+                                "bound": "mfma", "achieved": (pmm["work"] / (pmm["ms"] * 1e-3) / 1e12) if pmm["ms"] > 0 else 0.0,
+                                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": (pmm["work"] / (pmm["ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if pmm["ms"] > 0 else 0.0,
+                                "launches": pmm["launches"], "share_of_step_time": pmm["ms"] * 1e-3 / dt},
+            "roofline_inorm": {"bound": "hbm", "achieved": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9) if nrm["ms"] > 0 else 0.0,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if nrm["ms"] > 0 else 0.0,
+                               "share_of_step_time": nrm["ms"] * 1e-3 / dt},
+            "train": train,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, H, L, T)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,13 @@ inline int check_launch(const char* what) {
     if (_rc != DPPM_OK) return _rc; \
   } while (0)
 
+// Opt-in launch timing (bench / profiling only): when enabled, selected launches are bracketed by HIP events on
+// their own stream and summed per kernel class by dppm_prof_end().  Disabled (the default) it costs one branch.
+enum ProfClass { PROF_LINEAR = 0, PROF_PLANE_MM = 1, PROF_WGRAD = 2, PROF_NORM = 3, PROF_NCLASS = 4 };
+bool prof_enabled();
+void prof_before(hipStream_t st);
+void prof_after(hipStream_t st, int cls, double work);
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -46,6 +46,7 @@ struct GemmArgs {
   const float* dact;       // same layout as C: multiply by LeakyReLU'(dact)
   long dact_bs;
   int accumulate;          // C += result
+  int prof_class;          // ProfClass of this launch (measurement hooks only)
   float* rowsum;           // [gridDim.z][M] row sums of the A operand over this block's K range (K-minor A only), or null
 };
 
@@ -124,7 +125,9 @@ __device__ __forceinline__ void tile_store(const float4* r, float* __restrict__ 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR>
+// TAG only separates otherwise identical instantiations into distinct kernel symbols (0 linear, 1 plane, 2 wgrad) so that
+// rocprofv3 --stats reports them separately.
+template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, int TAG>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM, TN = BN / WN;      // per-wave tile
@@ -279,10 +282,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
 template <int BM, int BN, int WM, int WN>
 inline int launch_gemm_cfg(const GemmArgs& a, int batch_z, bool a_kmajor, bool b_kmajor, hipStream_t st) {
   dim3 grid(cdiv(a.n_store > a.N ? a.n_store : a.N, BN), cdiv(a.M, BM), batch_z), block(256);
-  if (!a_kmajor && b_kmajor) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, a);
-  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, a);
-  else if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, a);
-  else return fail(DPPM_E_UNSUPPORTED, "gemm: A K-major with B K-minor is not instantiated");
+  const int tag = a.prof_class;
+#define DPPM_GEMM_LAUNCH(AK, BKM, TAG) \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_f32_kernel<BM, BN, WM, WN, AK, BKM, TAG>), grid, block, 0, st, a)
+  if (tag == PROF_LINEAR) {
+    if (!a_kmajor && b_kmajor) DPPM_GEMM_LAUNCH(false, true, 0);
+    else if (a_kmajor && b_kmajor) DPPM_GEMM_LAUNCH(true, true, 0);
+    else return fail(DPPM_E_UNSUPPORTED, "gemm(linear): operand layout not instantiated");
+  } else if (tag == PROF_PLANE_MM) {
+    if (!a_kmajor && b_kmajor) DPPM_GEMM_LAUNCH(false, true, 1);
+    else if (a_kmajor && b_kmajor) DPPM_GEMM_LAUNCH(true, true, 1);
+    else if (!a_kmajor && !b_kmajor) DPPM_GEMM_LAUNCH(false, false, 1);
+    else return fail(DPPM_E_UNSUPPORTED, "gemm(plane): A^T * B^T is not instantiated");
+  } else if (tag == PROF_WGRAD) {
+    if (!a_kmajor && !b_kmajor) DPPM_GEMM_LAUNCH(false, false, 2);
+    else return fail(DPPM_E_UNSUPPORTED, "gemm(wgrad): operand layout not instantiated");
+  } else {
+    return fail(DPPM_E_INVALID, "gemm: unknown class %d", tag);
+  }
+#undef DPPM_GEMM_LAUNCH
   return check_launch("gemm_f32");
 }
 
@@ -290,9 +308,19 @@ inline int launch_gemm_cfg(const GemmArgs& a, int batch_z, bool a_kmajor, bool b
 inline int launch_gemm(const GemmArgs& a, int batch_z, bool a_kmajor, bool b_kmajor, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || batch_z <= 0) return fail(DPPM_E_INVALID, "gemm: empty problem M=%d N=%d z=%d", a.M, a.N, batch_z);
   if (batch_z > 65535) return fail(DPPM_E_INVALID, "gemm: batch %d exceeds grid.z limit", batch_z);
-  if (a.M > 64) return launch_gemm_cfg<128, 128, 2, 2>(a, batch_z, a_kmajor, b_kmajor, st);
-  if (a.M > 32) return launch_gemm_cfg<64, 128, 2, 2>(a, batch_z, a_kmajor, b_kmajor, st);
-  return launch_gemm_cfg<32, 128, 1, 4>(a, batch_z, a_kmajor, b_kmajor, st);
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  int rc;
+  if (a.M > 64) rc = launch_gemm_cfg<128, 128, 2, 2>(a, batch_z, a_kmajor, b_kmajor, st);
+  else if (a.M > 32) rc = launch_gemm_cfg<64, 128, 2, 2>(a, batch_z, a_kmajor, b_kmajor, st);
+  else rc = launch_gemm_cfg<32, 128, 1, 4>(a, batch_z, a_kmajor, b_kmajor, st);
+  if (prof) {
+    double k = 0;
+    for (int i = 0; i < a.nseg; ++i) k += a.seg[i].K;
+    const double batch = a.nsplit > 1 ? (double)batch_z / a.nsplit : (double)batch_z;
+    prof_after(st, a.prof_class, 2.0 * a.M * a.N * k * batch);
+  }
+  return rc;
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }

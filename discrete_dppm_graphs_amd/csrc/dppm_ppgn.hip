@@ -332,6 +332,7 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
   a.mul = mulmask; a.mul_bs = c.P; a.mul_ld = 0; a.mul_div = 1;
   a.dact = dact; a.dact_bs = dact_bs;
   a.accumulate = accumulate ? 1 : 0;
+  a.prof_class = PROF_LINEAR;
   return launch_gemm(a, c.B, /*a_kmajor=*/s0.w_trans, /*b_kmajor=*/true, c.st);
 }
 
@@ -351,6 +352,7 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
   a.M = M; a.N = Nw;
   a.C = slabs; a.c_bs = (long)M * Nw; a.ldc = Nw;
   a.rowsum = db ? rsum : nullptr;
+  a.prof_class = PROF_WGRAD;
   DPPM_TRY(launch_gemm(a, nz, false, false, c.st));
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, 256)), dim3(256), 0, c.st, slabs, nz, M, Nw, dW, ldo);
   DPPM_TRY(check_launch("reduce_slabs(dW)"));
@@ -380,6 +382,7 @@ int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batc
   // op(A) = A   : element (m,k) at A[m*ld + k]  -> K-minor ;  op(A) = A^T : (m,k) at A[k*ld + m] -> K-major
   // op(B) = B   : element (k,n) at B[k*ld + n]  -> K-major ;  op(B) = B^T : (k,n) at B[n*ld + k] -> K-minor
   const bool a_kmajor = ta, b_kmajor = !tb;
+  a.prof_class = PROF_PLANE_MM;
   return launch_gemm(a, batch, a_kmajor, b_kmajor, st);
 }
 
@@ -496,8 +499,10 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
     DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
     // masked instance norm, * mask; result lands in its slot of CAT   (model/ppgn.py:307,315-316)
+    if (prof_enabled()) prof_before(c.st);
     hipLaunchKernelGGL(inorm_fwd_kernel, dim3(B * H), dim3(NORM_THREADS), 0, c.st, y, hs, maskp, cat + (size_t)(2 + l * H) * P,
                        cat_bs, H, P, (float*)nullptr, c.at(w.rstd) + (size_t)l * B * H);
+    if (prof_enabled()) prof_after(c.st, PROF_NORM, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
     DPPM_TRY(check_launch("inorm_fwd"));
   }
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)

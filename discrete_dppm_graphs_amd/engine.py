@@ -1,0 +1,183 @@
+"""Device-resident training step and reverse sampling chains built on the C-ABI ops.
+
+This is the part of the reference's `fit` (ppgn_simple.py:65-94, ppgn_vlb.py:158-199) and `run_sample`
+(sample_ppgn_simple.py:70-88, sample_ppgn_vlb.py:111-131) that runs per batch, restated so that
+  * the whole batch goes through ONE denoiser call (the reference loops over graphs with batch 1),
+  * masks, noising, loss and gradient are fused kernels (the reference builds masks with Python loops on the CPU),
+  * nothing synchronises with the host inside a step (the reference calls .item() every step),
+  * parameters / gradients / Adam moments live in flat buffers, so data-parallel training needs exactly one
+    all-reduce per step (RCCL over xGMI) and one fused optimiser kernel.
+Random numbers are Philox draws keyed by (seed, global graph id, call offset): results are independent of how the
+graphs are sharded over GPUs.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------- schedules
+def sigma_lin(sigma_list):
+    """beta_t from the cumulative flip probabilities (ppgn_vlb.py:27-34 == sample_ppgn_vlb.py:28-35)."""
+    sigmas = []
+    for g, sigma in enumerate(sigma_list):
+        if sigma < 1.0e-5:
+            sigmas.append(0.0)
+            continue
+        sigmas.append(((1 - sigma) - (1 - sigma_list[g - 1])) / (1 - 2 * (1 - sigma_list[g - 1])))
+    return sigmas
+
+
+def schedule_simple(noise_num):
+    """Descending sigmas the simple sampler walks (sample_ppgn_simple.py:45-47,81-82)."""
+    s = torch.linspace(0, 1 / 2, noise_num).tolist()
+    s.sort()
+    return [s[len(s) - c - 1] for c in range(len(s))]
+
+
+def schedule_vlb(noise_num):
+    """(sigmatilde_t, beta_t, sigmatilde_{t-1}) for t = T..1 (sample_ppgn_vlb.py:67-70,122-126)."""
+    s = torch.linspace(0, 1 / 2, noise_num + 1).tolist()
+    s.sort()
+    beta = sigma_lin(s)
+    n = len(s)
+    return [(s[n - c - 1], beta[n - c - 1], s[n - c - 2]) for c in range(n - 1)]
+
+
+# ---------------------------------------------------------------------------------------------- flat parameters
+class FlatState:
+    """Used parameters of a `Powerful` re-homed into one contiguous float32 buffer (each nn.Parameter becomes a view,
+    names and shapes unchanged), plus a flat gradient bucket and Adam moments.  Unused parameters (time_mlp,
+    feature_extractors) never receive gradients in the reference either and are left alone, exactly as
+    torch.optim.Adam skips parameters whose .grad is None."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        self.names = model.used_param_names()
+        params = model._used_params()
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatState: move the model to the GPU first (no CPU fallback)")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]     # keep every view 16-byte aligned
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+        n = self.offsets[-1]
+        self.flat = torch.zeros(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        grads = {}
+        for name, p, off in zip(self.names, params, self.offsets):
+            view = self.flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            grads[name] = self.grad[off:off + p.numel()].view_as(p)
+        self.grad_views = grads
+        self.grad_pack = ops.ParamPack(grads, model.num_layers, model.hidden)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        model._pack_cache = None
+
+    def numel(self):
+        return self.flat.numel()
+
+    def all_reduce(self, group=None):
+        """Sum the flat gradient bucket over the data-parallel ranks (one collective per step)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+
+    def adam_step(self, lr=None):
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr, self.betas[0],
+                      self.betas[1], self.eps, self.weight_decay, self.step_count)
+
+    def publish_grads(self):
+        """Expose the flat bucket as .grad on the parameters (for callers that want to inspect or clip)."""
+        for name, p in zip(self.names, self.model._used_params()):
+            p.grad = self.grad_views[name]
+
+
+# ---------------------------------------------------------------------------------------------- training steps
+def node_flags(adj):
+    """train_node_flag_b = adj.sum(-1).gt(1e-5) (ppgn_simple.py:70)."""
+    return adj.sum(-1).gt(1e-5).to(torch.float32)
+
+
+def train_step_simple(model, state, adj, sigmas, seed, offset, graph_id0=0, B_global=None, group=None, lr=None):
+    """One optimiser step of the simple (BCE) objective on a device-resident batch `adj` [B,N,N].
+    sigmas: B doubles (the reference draws np.random.uniform(0, .5, B), ppgn_simple.py:67).  Returns the loss as a
+    0-d float64 device tensor (this rank's share of the global mean; sum over ranks for the global value)."""
+    B = adj.shape[0]
+    flags = node_flags(adj)
+    A_t, target = ops.edgeflip(adj, flags, sigmas, seed=seed, graph_id0=graph_id0, offset=offset)
+    mask = ops.generate_mask(flags)
+    sig_dev = torch.as_tensor(np.asarray(sigmas, dtype=np.float64), device=adj.device)
+
+    def loss_grad(logits):
+        return ops.loss_bce(logits, target, sig_dev, mask, B_global=B_global or B)
+
+    loss, _ = model.forward_backward(A_t, mask, np.asarray(sigmas, dtype=np.float64), loss_grad, state.grad_pack)
+    state.all_reduce(group)
+    state.adam_step(lr)
+    return loss
+
+
+def vlb_batch_schedule(T, t_idx):
+    """Per-graph (sigmatilde_t, beta_t, sigmatilde_{t-1}=st-st/t) as fit builds them (ppgn_vlb.py:161-168, :85-87)."""
+    line = torch.linspace(0, 1 / 2, T + 1).tolist()
+    beta = sigma_lin(line)
+    st = np.asarray([line[i] for i in t_idx], dtype=np.float64)
+    bt = np.asarray([beta[i] for i in t_idx], dtype=np.float64)
+    st1 = st - st / np.asarray(t_idx, dtype=np.float64)
+    return np.stack([st, bt, st1], 1)
+
+
+def train_step_vlb(model, state, adj, t_idx, T, seed, offset, graph_id0=0, group=None, lr=None):
+    """One optimiser step of the VLB objective; t_idx: B integers in [1, T] (ppgn_vlb.py:161)."""
+    flags = node_flags(adj)
+    sched = vlb_batch_schedule(T, t_idx)
+    A_t, _ = ops.edgeflip(adj, flags, sched[:, 0], seed=seed, graph_id0=graph_id0, offset=offset, want_target=False)
+    mask = ops.generate_mask(flags)
+    sched_dev = torch.as_tensor(sched, device=adj.device)
+
+    def loss_grad(logits):
+        return ops.loss_vlb(logits, A_t, adj, sched_dev, mask)
+
+    loss, _ = model.forward_backward(A_t, mask, sched[:, 0], loss_grad, state.grad_pack)
+    state.all_reduce(group)
+    state.adam_step(lr)
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------- sampling chains
+@torch.no_grad()
+def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None):
+    """x_T ~ Bern(1/2), then for sigma descending: re-noise x0_hat to sigma, predict flips, sample, XOR
+    (sample_ppgn_simple.py:70-88).  flags [B,N] float32 on the GPU.  Returns the final adjacency [B,N,N]."""
+    mask = ops.generate_mask(flags)
+    x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
+    a_t = torch.empty_like(x)
+    logits = torch.empty_like(x)
+    for c, sigma in enumerate(schedule_simple(noise_num)):
+        ops.edgeflip(x, flags, sigma, seed=seed, graph_id0=graph_id0, offset=1 + 2 * c, want_target=False, out=a_t)
+        model.infer(a_t, mask, sigma, out=logits)
+        ops.reverse_step_simple(a_t, logits, flags, seed=seed, graph_id0=graph_id0, offset=2 + 2 * c, out=x)
+        if record is not None:
+            record(c, a_t, logits, x)
+    return x
+
+
+@torch.no_grad()
+def sample_chain_vlb(model, flags, noise_num, seed, graph_id0=0, record=None):
+    """x_T ~ Bern(1/2), then t = T..1: predict flips, mix posteriors, sample A_{t-1} (sample_ppgn_vlb.py:111-131)."""
+    mask = ops.generate_mask(flags)
+    x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
+    y = torch.empty_like(x)
+    logits = torch.empty_like(x)
+    for c, (st, beta, st1) in enumerate(schedule_vlb(noise_num)):
+        model.infer(x, mask, st, out=logits)
+        ops.reverse_step_vlb(x, logits, flags, st, beta, st1, seed=seed, graph_id0=graph_id0, offset=1 + c, out=y)
+        if record is not None:
+            record(c, x, logits, y)
+        x, y = y, x
+    return x

@@ -298,3 +298,20 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
         _chk(t, n, (param.numel(),))
     check(lib.dppm_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), C.c_size_t(param.numel()), lr, beta1,
                              beta2, eps, weight_decay, int(step), grad_scale, _stream()), "dppm_adam_step")
+
+
+PROF_CLASSES = ("linear_gemm", "plane_matmul", "wgrad_gemm", "inorm")
+
+
+def prof_begin(max_records=200000):
+    check(lib.dppm_prof_begin(int(max_records)), "dppm_prof_begin")
+
+
+def prof_end():
+    """-> {class: {"ms": device time, "work": FLOPs (bytes for inorm), "launches": n}}, truncated flag."""
+    n = len(PROF_CLASSES)
+    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_long * n)()
+    rc = lib.dppm_prof_end(ms, work, cnt, n)
+    if rc < 0:
+        check(rc, "dppm_prof_end")
+    return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, k in enumerate(PROF_CLASSES)}, rc == 1

@@ -188,6 +188,18 @@ int dppm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (no counterpart in the reference; used by bench.py only).
+ * dppm_prof_begin arms per-launch HIP-event timing of the GEMM-family and norm kernels (events are recorded on the
+ * stream each kernel is launched on); dppm_prof_end waits for them and returns, per kernel class
+ * (0 = per-position linear GEMMs, 1 = per-channel N x N contraction, 2 = weight-gradient GEMMs, 3 = instance norm),
+ * the summed device time [ms], the summed algorithmic work (FLOPs for 0-2, bytes for 3) and the launch count.
+ * Returns 1 if more than max_records launches happened (totals then cover the first max_records only).
+ * Process-global, not thread-safe; arm it from one thread with no other caller active.
+ * ---------------------------------------------------------------------------------------------- */
+int dppm_prof_begin(int max_records);
+int dppm_prof_end(double* ms_per_class_host, double* work_per_class_host, long* launches_per_class_host, int nclass);
+
 #ifdef __cplusplus
 }
 #endif
