@@ -13,8 +13,6 @@ Only the configuration that utils/loading_utils.py:98-119 builds is implemented 
 norm, cat_output, adj_out, layer_after_conv, no residual / project_first / node_out); anything else raises.
 All arithmetic happens in libdppm_hip.so; there is no PyTorch fallback.
 """
-import math
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -22,12 +20,6 @@ import torch.nn as nn
 from .. import ops
 
 SLOPE = 0.01
-
-
-def _linear_params(out_f, in_f, bias=True):
-    """nn.Linear's default initialisation (kaiming_uniform(a=sqrt(5)) / uniform bias), as parameters only."""
-    lin = nn.Linear(in_f, out_f, bias=bias)
-    return lin
 
 
 class _Seq(nn.Sequential):
@@ -66,8 +58,7 @@ class _PowerfulFn(torch.autograd.Function):
     """autograd bridge: forward/backward are single C-ABI calls; the workspace filled by forward is kept for backward."""
 
     @staticmethod
-    def forward(ctx, module, A, mask, sigma, *params):
-        training = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+    def forward(ctx, module, training, A, mask, sigma, *params):
         pack = module._pack()
         B, N, _ = A.shape
         ws = module._workspace(B, N, training, A.device)
@@ -87,7 +78,7 @@ class _PowerfulFn(torch.autograd.Function):
         gpack = ops.ParamPack(grads, module.num_layers, module.hidden)
         ops.ppgn_backward(ctx.pack, gpack, A, mask, sigma, dlogits.contiguous(), ctx.ws)
         ctx.ws = None
-        return (None, None, None, None) + tuple(grads[n] for n in names)
+        return (None, None, None, None, None) + tuple(grads[n] for n in names)
 
 
 class Powerful(nn.Module):
@@ -145,7 +136,10 @@ class Powerful(nn.Module):
     def forward_cat(self, A, node_features, mask, noiselevel):
         del node_features   # ignored by the reference as well (model/ppgn.py:294)
         A, mask, sigma = self._prepare(A, mask, noiselevel)
-        logits = _PowerfulFn.apply(self, A, mask, sigma, *self._used_params())
+        params = self._used_params()
+        # grad mode is off inside Function.forward, so the decision to keep the backward workspace is taken here
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        logits = _PowerfulFn.apply(self, training, A, mask, sigma, *params)
         return logits.unsqueeze(-1)
 
     # ------------------------------------------------------------------ engine surface (no autograd)

@@ -1,0 +1,262 @@
+"""GPU tests of the host-side mirror: Powerful as an nn.Module (autograd path, reference calling conventions), the
+device-resident train step against oracle autograd + torch.optim.Adam, the sampling chains step by step against the
+oracle, data-parallel normalisation, and train_main / sample_main on a small synthetic dataset."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype).cuda().contiguous()
+
+
+def make_model(L, H, N, seed=0, weights=None):
+    from discrete_dppm_graphs_amd.model.ppgn import Powerful
+    torch.manual_seed(seed)
+    m = Powerful(num_layers=L, hidden=H, hidden_final=H, n_nodes=N, normalization="instance", adj_out=True,
+                 input_features=2, dropout_p=1e-6)
+    if weights is not None:
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in weights.items()}, strict=False)
+    return m.cuda()
+
+
+def rand_graphs(rng, B, N):
+    A = np.zeros((B, N, N), np.float32)
+    for b in range(B):
+        n = int(rng.integers(max(3, N // 2), N + 1))
+        up = np.triu((rng.random((n, n)) < 0.3).astype(np.float32), 1)
+        for i in range(n - 1):
+            up[i, i + 1] = 1
+        A[b, :n, :n] = up + up.T
+    return A
+
+
+def test_module_reference_calling_convention_and_autograd():
+    """fit() of the reference: B batch-1 keyword calls, cat, loss_func_bce, one backward (ppgn_simple.py:84-92)."""
+    from discrete_dppm_graphs_amd.ppgn_simple import loss_func_bce
+    from discrete_dppm_graphs_amd.utils.graph_utils import generate_mask
+    g = np.load(os.path.join(G, "g1_ppgn_n18_h32_l6.npz"))
+    L, H, N = int(g["L"]), int(g["H"]), int(g["N"])
+    W = {k[3:]: g[k] for k in g.files if k.startswith("w::")}
+    model = make_model(L, H, N, weights=W)
+    model.train()
+    A_t, flags, sigmas = dev(g["A_t"]), dev(g["flags"]), g["sigmas"].tolist()
+    score, masks = [], []
+    for i, s in enumerate(sigmas):
+        mask = generate_mask(flags[i:i + 1])
+        out = model(A=A_t[i].unsqueeze(0), node_features=A_t[i], mask=mask, noiselevel=s)
+        assert out.shape == (1, N, N, 1)
+        score.append(out)
+        masks.append(mask)
+    score = torch.cat(score, 0).squeeze(-1)
+    loss = loss_func_bce(score, dev(g["targets"]), sigmas, None, torch.cat(masks, 0))
+    loss.backward()
+    assert loss.dtype == torch.float64
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(score.detach().cpu().numpy(), g["logits"], rtol=1e-4, atol=5e-6)
+    gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("g::"))
+    for n, p in model.named_parameters():
+        if "g::" + n in g.files:
+            assert np.abs(p.grad.cpu().numpy() - g["g::" + n]).max() <= 5e-4 * np.abs(g["g::" + n]).max() + 1e-5 * gmax, n
+        else:
+            assert p.grad is None, n            # time_mlp / feature_extractors never get gradients (as in the reference)
+    # positional sampler convention model(feat, A, mask, noise), one scalar sigma for the batch, eval mode
+    model.eval()
+    with torch.no_grad():
+        lb = model(None, A_t, dev(g["mask"]), float(sigmas[0])).squeeze(-1)
+    np.testing.assert_allclose(lb.cpu().numpy(), g["logits_batched_sigma0"], rtol=1e-4, atol=5e-6)
+
+
+def _oracle_step(W, A0, sigmas, U, L, lr, opt_state, B_global=None):
+    from oracle import diffusion as od, ppgn as op
+    flags = (A0.sum(-1) > 1e-5).astype(np.float32)
+    a_t, tgt = od.discretenoise(A0, flags, sigmas, U)
+    mask = od.generate_mask(flags)
+    logits = op.powerful_forward(W, a_t, mask, sigmas, L).squeeze(-1)
+    loss = od.loss_bce(logits, tgt, sigmas, mask)
+    for v in W.values():
+        v.grad = None
+    loss.backward()
+    opt_state.step()
+    return loss.item()
+
+
+def test_train_steps_match_oracle_autograd_plus_torch_adam():
+    """Three optimiser steps of engine.train_step_simple vs (oracle forward + autograd + torch.optim.Adam) on the CPU,
+    fed the same Philox uniforms."""
+    from discrete_dppm_graphs_amd import engine
+    from oracle import philox, ppgn as op
+    rng = np.random.default_rng(11)
+    B, N, H, L = 5, 14, 16, 2
+    A0 = rand_graphs(rng, B, N)
+    Wref = {k: v.clone().requires_grad_(True) for k, v in op.init_weights(L, H, seed=3).items()}
+    model = make_model(L, H, N, weights={k: v.detach().numpy() for k, v in Wref.items()})
+    model.train()
+    state = engine.FlatState(model, lr=1e-2, weight_decay=1e-3)
+    opt = torch.optim.Adam([Wref[n] for n in model.used_param_names()], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+    seed = 77
+    for step in range(3):
+        sig = rng.uniform(0, 0.5, size=B)
+        U = philox.uniform_pairs(seed, np.arange(100, 100 + B), step, N)
+        ref_loss = _oracle_step(Wref, A0, sig, U, L, 1e-2, opt)
+        loss = engine.train_step_simple(model, state, dev(A0), sig, seed, step, graph_id0=100)
+        np.testing.assert_allclose(loss.item(), ref_loss, rtol=2e-5)
+    sd = dict(model.named_parameters())
+    for n in model.used_param_names():
+        np.testing.assert_allclose(sd[n].detach().cpu().numpy(), Wref[n].detach().numpy(), rtol=2e-3, atol=2e-5, err_msg=n)
+
+
+def test_vlb_train_step_matches_oracle():
+    from discrete_dppm_graphs_amd import engine
+    from oracle import diffusion as od, philox, ppgn as op
+    rng = np.random.default_rng(12)
+    B, N, H, L, T = 4, 12, 16, 2, 16
+    A0 = rand_graphs(rng, B, N)
+    Wref = {k: v.clone().requires_grad_(True) for k, v in op.init_weights(L, H, seed=4).items()}
+    model = make_model(L, H, N, weights={k: v.detach().numpy() for k, v in Wref.items()})
+    model.train()
+    state = engine.FlatState(model, lr=1e-3)
+    t_idx = np.array([1, T, 5, 9])
+    sched = engine.vlb_batch_schedule(T, t_idx)
+    U = philox.uniform_pairs(5, np.arange(B), 0, N)
+    flags = (A0.sum(-1) > 1e-5).astype(np.float32)
+    a_t, _ = od.discretenoise(A0, flags, sched[:, 0], U)
+    mask = od.generate_mask(flags)
+    logits = op.powerful_forward(Wref, a_t, mask, sched[:, 0], L).squeeze(-1)
+    line = torch.linspace(0, 0.5, T + 1).tolist()
+    ref = od.loss_vlb(logits, a_t, A0, od.vlb_train_scalars(sched[:, 0], t_idx, sched[:, 1]), mask)
+    ref.backward()
+    loss = engine.train_step_vlb(model, state, dev(A0), t_idx, T, 5, 0)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+    gmax = max(float(Wref[n].grad.abs().max()) for n in model.used_param_names())
+    for n in model.used_param_names():
+        got = state.grad_views[n].cpu().numpy()
+        want = Wref[n].grad.numpy()
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max() + 2e-5 * gmax, n
+
+
+def test_data_parallel_normalisation_two_shards_equal_one():
+    """Gradients of the global batch == sum of the two shard gradients when both use B_global (what the all-reduce sums)."""
+    from discrete_dppm_graphs_amd import engine, ops
+    rng = np.random.default_rng(13)
+    B, N, H, L = 6, 16, 16, 2
+    A0 = dev(rand_graphs(rng, B, N))
+    sig = rng.uniform(0, 0.5, size=B)
+    model = make_model(L, H, N, seed=5)
+    state = engine.FlatState(model)
+
+    def grads(lo, hi):
+        adj = A0[lo:hi].contiguous()
+        flags = engine.node_flags(adj)
+        A_t, target = ops.edgeflip(adj, flags, sig[lo:hi], seed=9, graph_id0=lo, offset=0)
+        mask = ops.generate_mask(flags)
+        loss, _ = model.forward_backward(A_t, mask, sig[lo:hi], lambda lg: ops.loss_bce(lg, target, sig[lo:hi], mask, B_global=B),
+                                         state.grad_pack)
+        return loss.item(), state.grad.clone()
+
+    l_full, g_full = grads(0, B)
+    l_a, g_a = grads(0, 2)
+    l_b, g_b = grads(2, B)
+    np.testing.assert_allclose(l_a + l_b, l_full, rtol=1e-6)
+    scale = float(g_full.abs().max())
+    assert float((g_a + g_b - g_full).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("kind", ["simple", "vlb"])
+def test_sampling_chain_stepwise_vs_oracle(kind):
+    """Every step of the device chain is re-derived by the oracle from the device's own inputs: Philox uniforms, the
+    re-noised A_t (bit-exact), logits (tolerance) and the sampled result (bit-exact except where u is within 2e-6 of p,
+    the only place one ulp of sigmoid can matter)."""
+    from discrete_dppm_graphs_amd import engine
+    from oracle import diffusion as od, philox, ppgn as op
+    rng = np.random.default_rng(14)
+    B, N, H, L, T = 3, 15, 16, 2, 6
+    nn_ = np.array([15, 9, 12])
+    flags = (np.arange(N)[None, :] < nn_[:, None]).astype(np.float32)
+    W = op.init_weights(L, H, seed=6)
+    model = make_model(L, H, N, weights={k: v.numpy() for k, v in W.items()}).eval()
+    seed, gid0 = 4242, 50
+    rec = []
+    chain = engine.sample_chain_simple if kind == "simple" else engine.sample_chain_vlb
+    final = chain(model, dev(flags), T, seed, gid0, record=lambda c, a, lg, x: rec.append((a.cpu().numpy().copy(), lg.cpu().numpy().copy(), x.cpu().numpy().copy())))
+    ids = np.arange(gid0, gid0 + B)
+    mask = od.generate_mask(flags)
+    x = od.gen_init_data(flags, philox.uniform_pairs(seed, ids, 0, N)).numpy()
+    sched = od.schedule_simple(T) if kind == "simple" else od.schedule_vlb(T)
+    assert len(rec) == T
+    for c in range(T):
+        a_dev, lg_dev, x_dev = rec[c]
+        if kind == "simple":
+            s = sched[len(sched) - c - 1]
+            a_t, _ = od.discretenoise(x, flags, s, philox.uniform_pairs(seed, ids, 1 + 2 * c, N))
+            assert np.array_equal(a_t.numpy(), a_dev)
+            u = philox.uniform_pairs(seed, ids, 2 + 2 * c, N)
+            probs = torch.sigmoid(torch.from_numpy(lg_dev))
+            want = od.reverse_step_simple(a_t, probs, flags, u).numpy()
+            sig_c = s
+        else:
+            st, beta, st1 = sched[c]
+            assert np.array_equal(x, a_dev)
+            u = philox.uniform_pairs(seed, ids, 1 + c, N)
+            probs = torch.sigmoid(torch.from_numpy(lg_dev))
+            want = od.reverse_step_vlb(a_dev, probs, flags, od.vlb_scalars(st, beta, st1), u).numpy()
+            sig_c = st
+        ref_logits = op.powerful_forward(W, a_dev, mask, sig_c, L).squeeze(-1).numpy()
+        assert np.abs(ref_logits - lg_dev).max() <= 1e-3 * max(np.abs(ref_logits).max(), 1e-3)
+        assert int((want != x_dev).sum()) <= 2, f"step {c}"
+        x = x_dev                      # continue from the device state
+    assert np.array_equal(final.cpu().numpy(), x)
+    assert np.array_equal(x, x.transpose(0, 2, 1)) and float((x * (1 - mask.numpy())).sum()) == 0
+
+
+def test_sampling_is_independent_of_sharding():
+    """Graph ids are global: sampling graphs [0,4) in one call equals sampling [0,2) and [2,4) separately."""
+    from discrete_dppm_graphs_amd import engine
+    model = make_model(2, 16, 12, seed=8).eval()
+    flags = torch.ones(4, 12, device="cuda")
+    flags[1, 8:] = 0
+    full = engine.sample_chain_vlb(model, flags, 5, 99, graph_id0=0)
+    a = engine.sample_chain_vlb(model, flags[:2].contiguous(), 5, 99, graph_id0=0)
+    b = engine.sample_chain_vlb(model, flags[2:].contiguous(), 5, 99, graph_id0=2)
+    assert torch.equal(full, torch.cat([a, b]))
+
+
+@pytest.mark.parametrize("which", ["simple", "vlb"])
+def test_train_main_and_sample_main_end_to_end(tmp_path, monkeypatch, which):
+    """train_main on a tiny synthetic dataset (2 epochs), checkpoints in the reference's dict format, then sample_main."""
+    import discrete_dppm_graphs_amd.ppgn_simple as ps
+    import discrete_dppm_graphs_amd.ppgn_vlb as pv
+    from discrete_dppm_graphs_amd import sample_ppgn_simple, sample_ppgn_vlb
+    from discrete_dppm_graphs_amd.utils.easydict import EasyDict
+    from discrete_dppm_graphs_amd.utils import arg_helper
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(15)
+    os.makedirs("data")
+    adjs = rand_graphs(rng, 20, 10)
+    sizes = (adjs.sum(-1) > 0).sum(-1)
+    np.savez(os.path.join("data", "toy.npz"), adjs=adjs, sizes=sizes)
+    open(os.path.join("data", "toy.txt"), "w").write("toy")
+    cfg = EasyDict(exp_dir="exp", exp_name="toy", seed=1234, dataset=dict(dataset_size=20, max_node_num=10, name="toy"),
+                   model=dict(name="ppgn"), test=dict(batch_size=4, split=0.2),
+                   train=dict(batch_size=8, lr_dacey=0.999, lr_init=0.01, max_epoch=2, sample_interval=1, save_interval=1, weight_decay=0.0),
+                   eval_from=0, samplesize=8, finalinterval=2, num_layers=2, hidden=16, hidden_final=16, dropout=1e-6, n_nodes=10,
+                   normalization="instance", noise_mlp=False, num_levels=[4], noisetype="switched")
+    arg_helper.process_config(cfg)
+    args = types.SimpleNamespace(log_level="INFO", comment="e2e")
+    mod, smod = (ps, sample_ppgn_simple) if which == "simple" else (pv, sample_ppgn_vlb)
+    state = mod.train_main(cfg, args)
+    assert state.step_count == 2 * 2          # 16 training graphs / batch 8, 2 epochs
+    for sub in ("", "bestloss"):
+        path = os.path.join(cfg.model_save_dir, sub, "toy.pth")
+        ckp = torch.load(path, weights_only=True)
+        assert {"model", "sigma_list", "config", "epoch", "train_loss", "test_loss", "optimizer_state_dict", "scheduler_state_dict"} <= set(ckp)
+        assert "convs.1.m4.0.weight" in ckp["model"] and "time_mlp.0.weight" in ckp["model"]
+        assert np.isfinite(ckp["train_loss"])
+    res = smod.sample_main(cfg, cfg.model_save_dir, 1, 4)
+    assert "degree" in res and np.isfinite(res["degree"])
