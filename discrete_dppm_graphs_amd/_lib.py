@@ -58,6 +58,8 @@ SIGNATURES = {
                                     C.c_int, c_stream]),
     "dppm_linear_fwd": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_long, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_long,
                                   C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "dppm_mlp_pair_fwd": (C.c_int, [c_f32p, C.c_long, C.POINTER(PpgnLayer), C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
+                                    C.c_int, c_stream]),
     "dppm_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "dppm_linear_wgrad": (C.c_int, [c_f32p, C.c_long, c_f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                     c_f32p, C.c_void_p, C.c_size_t, c_stream]),

@@ -10,6 +10,8 @@
 //     two-segment K loop and the readout reads the layer outputs where they already lie (buffer CAT).
 // so the reference's permutes and cats never cost a byte.  All GEMMs run on v_mfma_f32_32x32x2_f32 (dppm_gemm.h).
 #include "dppm_gemm.h"
+#include "dppm_wstat.h"
+#include <cstdlib>
 
 namespace dppm {
 namespace {
@@ -295,6 +297,12 @@ struct Ctx {
 
 struct Geo { int B, P; hipStream_t st; };
 
+// A/B switch for measurements: DPPM_DISABLE_WSTAT=1 routes the H = 128 linears through the generic GEMM family.
+inline bool use_wstat(int H) {
+  static const bool off = getenv("DPPM_DISABLE_WSTAT") != nullptr;
+  return H == WS_H && !off;
+}
+
 GemmArgs base_args() {
   GemmArgs a{};
   a.nseg = 1; a.nsplit = 1; a.kchunk = 0; a.scale_div = 1; a.mul_div = 1;
@@ -334,6 +342,26 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
   a.accumulate = accumulate ? 1 : 0;
   a.prof_class = PROF_LINEAR;
   return launch_gemm(a, c.B, /*a_kmajor=*/s0.w_trans, /*b_kmajor=*/true, c.st);
+}
+
+// m1, m2: Linear -> LeakyReLU -> Linear, then * mask   (model/ppgn.py:58-59)
+int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long x_bs, const float* maskp, float* o1, float* o2,
+             float* hid1, float* hid2, bool save_hid) {
+  const long hs = (long)H * c.P;
+  if (use_wstat(H)) {   // weight-stationary fused pair: X read once, hidden activations stay in LDS unless training
+    WsArgs wa{};
+    wa.X0 = x; wa.x0_bs = x_bs;
+    wa.W0 = q.m1_w0; wa.W1 = q.m2_w0; wa.W2 = q.m1_w1; wa.W3 = q.m2_w1; wa.ldw01 = H; wa.ldw23 = H;
+    wa.b0 = q.m1_b0; wa.b1 = q.m2_b0; wa.b2 = q.m1_b1; wa.b3 = q.m2_b1;
+    wa.maskp = maskp; wa.Y0 = o1; wa.Y1 = o2; wa.y_bs = hs;
+    wa.H0 = save_hid ? hid1 : nullptr; wa.H1 = save_hid ? hid2 : nullptr;
+    wa.B = c.B; wa.P = c.P;
+    return ws_launch(WS_MLP2, save_hid, wa, c.st);
+  }
+  DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
+  DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, false, hid1, hs, H}, nullptr, q.m1_b1, 0, maskp, nullptr, 0, o1, hs, false));
+  DPPM_TRY(linear(c, H, LinArgs{q.m2_w0, H, false, x, x_bs, H}, nullptr, q.m2_b0, 1, nullptr, nullptr, 0, hid2, hs, false));
+  return linear(c, H, LinArgs{q.m2_w1, H, false, hid2, hs, H}, nullptr, q.m2_b1, 0, maskp, nullptr, 0, o2, hs, false);
 }
 
 // dW (M x Nw, pitch ldo) = sum_b dY[b] (M x P) * X[b]^T (P x Nw) ; optional db = row sums of dY
@@ -429,6 +457,17 @@ extern "C" int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float
                 Y, y_bs, accumulate != 0);
 }
 
+extern "C" int dppm_mlp_pair_fwd(const float* X, long x_bs, const dppm_ppgn_layer* q, int H, const float* maskp, float* o1, float* o2,
+                                 float* hid1, float* hid2, int B, int P, void* stream) {
+  DPPM_REQUIRE(X && q && o1 && o2, "dppm_mlp_pair_fwd: null pointer");
+  DPPM_REQUIRE(q->m1_w0 && q->m1_b0 && q->m1_w1 && q->m1_b1 && q->m2_w0 && q->m2_b0 && q->m2_w1 && q->m2_b1, "dppm_mlp_pair_fwd: null weight");
+  DPPM_REQUIRE(H >= 4 && H % 4 == 0 && B > 0 && P > 0 && P % 4 == 0, "dppm_mlp_pair_fwd: H=%d B=%d P=%d", H, B, P);
+  DPPM_REQUIRE((hid1 == nullptr) == (hid2 == nullptr), "dppm_mlp_pair_fwd: pass both hidden buffers or none");
+  DPPM_REQUIRE(H == WS_H || hid1, "dppm_mlp_pair_fwd: H != 128 needs hid1/hid2 as scratch");
+  DPPM_REQUIRE(aligned16(X) && aligned16(o1) && aligned16(o2) && x_bs % 4 == 0, "dppm_mlp_pair_fwd: planes must be 16-byte aligned");
+  return mlp_pair(Geo{B, P, as_stream(stream)}, *q, H, X, x_bs, maskp, o1, o2, hid1, hid2, hid1 != nullptr);
+}
+
 extern "C" size_t dppm_linear_wgrad_workspace_bytes(int M, int Nw, int B, int P) {
   if (M <= 0 || Nw <= 0 || B <= 0 || P <= 0) return 0;
   const size_t nz = (size_t)B * wgrad_nsplit(B, P);
@@ -488,16 +527,20 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     float* o2 = training ? c.at(w.o2) + (size_t)l * w.S : c.at(w.tmp[2]);
     float* mm = training ? c.at(w.mm) + (size_t)l * w.S : c.at(w.tmp[0]);
     float* y = c.at(w.tmp[3]);
-    // m1, m2: Linear -> LeakyReLU -> Linear, then * mask   (model/ppgn.py:58-59)
-    DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
-    DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, false, hid1, hs, H}, nullptr, q.m1_b1, 0, maskp, nullptr, 0, o1, hs, false));
-    DPPM_TRY(linear(c, H, LinArgs{q.m2_w0, H, false, x, x_bs, H}, nullptr, q.m2_b0, 1, nullptr, nullptr, 0, hid2, hs, false));
-    DPPM_TRY(linear(c, H, LinArgs{q.m2_w1, H, false, hid2, hs, H}, nullptr, q.m2_b1, 0, maskp, nullptr, 0, o2, hs, false));
+    DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
     DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
-    LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
-    DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
+    if (use_wstat(H)) {
+      WsArgs wa{};
+      wa.X0 = mm; wa.x0_bs = hs; wa.X1 = x; wa.x1_bs = x_bs;
+      wa.W0 = q.m4_w; wa.W1 = q.m4_w + H; wa.ldw01 = 2 * H; wa.b0 = q.m4_b;
+      wa.Y0 = y; wa.y_bs = hs; wa.B = B; wa.P = P;
+      DPPM_TRY(ws_launch(WS_SUM2, false, wa, c.st));
+    } else {
+      LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
+      DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
+    }
     // masked instance norm, * mask; result lands in its slot of CAT   (model/ppgn.py:307,315-316)
     if (prof_enabled()) prof_before(c.st);
     hipLaunchKernelGGL(inorm_fwd_kernel, dim3(B * H), dim3(NORM_THREADS), 0, c.st, y, hs, maskp, cat + (size_t)(2 + l * H) * P,
@@ -508,7 +551,14 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)
   DPPM_TRY(linear(c, H, LinArgs{pr->cat_w, w.CT, false, cat, cat_bs, w.CT}, nullptr, pr->cat_b, 0, nullptr, nullptr, 0, c.at(w.R), hs, false));
   // out + LeakyReLU(after_conv(out)) ; final_lin   (model/ppgn.py:331-333)
-  DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, false, c.at(w.R), hs, H}, nullptr, pr->after_b, 1, nullptr, nullptr, 0, c.at(w.act), hs, false));
+  if (use_wstat(H)) {
+    WsArgs wa{};
+    wa.X0 = c.at(w.R); wa.x0_bs = hs; wa.W0 = pr->after_w; wa.ldw01 = H; wa.b0 = pr->after_b; wa.act = 1;
+    wa.Y0 = c.at(w.act); wa.y_bs = hs; wa.B = B; wa.P = P;
+    DPPM_TRY(ws_launch(WS_COLS, false, wa, c.st));
+  } else {
+    DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, false, c.at(w.R), hs, H}, nullptr, pr->after_b, 1, nullptr, nullptr, 0, c.at(w.act), hs, false));
+  }
   hipLaunchKernelGGL(final_fwd_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, c.st, c.at(w.R), c.at(w.act), pr->final_w, pr->final_b,
                      H, N, w.ld, logits);
   return check_launch("final_fwd");

@@ -263,6 +263,28 @@ def linear_fwd(W, X, bias=None, act=False, maskp=None, trans_w=False, out=None, 
     return Y
 
 
+def mlp_pair_fwd(X, weights, maskp=None, save_hidden=False):
+    """X: [B, H, P]; weights: dict with the ten `m1.0.weight` ... `m4.0.bias`-style keys of one layer (m4 unused).
+    -> (o1, o2, hid1 or None, hid2 or None)"""
+    X = _chk(X, "X")
+    B, H, P = X.shape
+    layer = PpgnLayer()
+    keep = []
+    for field, suffix in LAYER_FIELDS:
+        if field.startswith("m4"):
+            continue
+        t = _chk(weights[suffix], suffix, (H, H) if suffix.endswith("weight") else (H,))
+        keep.append(t)
+        setattr(layer, field, t.data_ptr())
+    o1, o2 = torch.empty_like(X), torch.empty_like(X)
+    need_hid = save_hidden or H != 128
+    h1 = torch.empty_like(X) if need_hid else None
+    h2 = torch.empty_like(X) if need_hid else None
+    check(lib.dppm_mlp_pair_fwd(_ptr(X), C.c_long(H * P), C.byref(layer), H, _ptr(maskp), _ptr(o1), _ptr(o2), _ptr(h1), _ptr(h2), B, P,
+                                _stream()), "dppm_mlp_pair_fwd")
+    return o1, o2, h1, h2
+
+
 def linear_wgrad(dY, X, want_bias=True):
     """dY: [B, M, P], X: [B, Nw, P] -> (dW [M, Nw], db [M] or None)."""
     dY = _chk(dY, "dY")

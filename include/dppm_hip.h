@@ -170,6 +170,14 @@ int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, float* u, long
 int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float* X, long x_bs, int K, const float* bias, int act,
                     const float* maskp, float* Y, long y_bs, int M, int B, int P, int accumulate, void* stream);
 
+/* The two per-position MLPs of one PPGN layer in one pass over X (model/ppgn.py:58-59):
+ *   o_k[b] = (W_k1 * LeakyReLU(W_k0 * X[b] + b_k0) + b_k1) * maskp[b],  k = 1, 2      (all matrices H x H, planes H x P).
+ * hid1 / hid2 (nullable, both or none): the hidden activations, written only when a backward pass will need them.
+ * H = 128 runs the weight-stationary fused kernel (hidden activations stay in LDS); other H use four GEMM launches and
+ * then need hid1 / hid2 as scratch (not nullable). */
+int dppm_mlp_pair_fwd(const float* X, long x_bs, const dppm_ppgn_layer* layer_host, int H, const float* maskp,
+                      float* o1, float* o2, float* hid1, float* hid2, int B, int P, void* stream);
+
 /* dW (M x Nw, row pitch ldo) = sum_b dY[b] (M x P) * X[b]^T (P x Nw), db (nullable) [M] = sum_{b,p} dY[b][m][p]:
  * the weight/bias gradient of the Linear above (split-K partial slabs + ordered reduction, bitwise reproducible).
  * workspace: dppm_linear_wgrad_workspace_bytes(M, Nw, B, P). */

@@ -18,7 +18,7 @@ def fwd(W, A, mask, sigma, L, dt):
     out = F.linear(out, W["layer_cat_lin.0.weight"], W["layer_cat_lin.0.bias"])
     out = out + F.leaky_relu(F.linear(out, W["after_conv.0.weight"], W["after_conv.0.bias"]), 0.01)
     return F.linear(out, W["final_lin.0.weight"], W["final_lin.0.bias"])
-for (B,N,H,L) in [(1,129,32,1)]:
+for (B,N,H,L) in [(2,60,128,2)]:
     rng = np.random.default_rng(B * 1000 + N)
     A, mask = rand_case(rng, B, N)
     sigma = rng.uniform(0, 0.5, size=B)
