@@ -11,6 +11,7 @@
 // so the reference's permutes and cats never cost a byte.  All GEMMs run on v_mfma_f32_32x32x2_f32 (dppm_gemm.h).
 #include "dppm_gemm.h"
 #include "dppm_wstat.h"
+#include "dppm_planemm.h"
 #include <cstdlib>
 
 namespace dppm {
@@ -397,6 +398,11 @@ int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float*
 // per-plane products for all (b,c): C = op(A) * op(B) * inv_norm[b] (* mask[b])
 int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batch, int n, int ld, bool ta, bool tb,
              const float* scale, const float* mask, int div) {
+  static const bool strip_off = getenv("DPPM_DISABLE_STRIPMM") != nullptr;   // A/B switch for measurements
+  if (plane_mm_supported(n) && !strip_off && aligned16(A) && aligned16(Bm) && aligned16(C)) {
+    PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};
+    return plane_mm_launch(pa, batch, /*a_kmajor=*/ta, /*b_kmajor=*/!tb, st);
+  }
   GemmArgs a = base_args();
   const long P = (long)n * ld;
   a.seg[0].A = A; a.seg[0].a_bs = P; a.seg[0].lda = ld;
