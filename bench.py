@@ -173,12 +173,12 @@ def main():
                                    f"{T} noise levels, {B} graphs/GPU per chain", "nodes": N, "hidden": H, "layers": L,
                        "noise_levels": T, "graphs_per_gpu": B, "parallelism": f"graph-sharded x{world}, no collective"},
             "model_tflops": graphs_per_s * T * F / 1e12,
-            "roofline": {"kernel": "gemm_f32_kernel<...,TAG=0> (per-position linear layers on v_mfma_f32_32x32x2_f32)",
+            "roofline": {"kernel": "per-position linear layers on v_mfma_f32_32x32x2_f32: wstat_kernel<MLP2|SUM2|COLS> (H=128) + gemm_f32_kernel<...,TAG=0> (in_lin, layer_cat_lin)",
                          "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": lin["launches"], "avg_launch_ms": lin["ms"] / max(lin["launches"], 1),
                          "share_of_step_time": lin["ms"] * 1e-3 / dt, "records_truncated": truncated},
-            "roofline_matmul": {"kernel": "gemm_f32_kernel<...,TAG=1> (per-channel N x N contraction, model/ppgn.py:62)",
+            "roofline_matmul": {"kernel": "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)",
                                 "bound": "mfma", "achieved": (pmm["work"] / (pmm["ms"] * 1e-3) / 1e12) if pmm["ms"] > 0 else 0.0,
                                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": (pmm["work"] / (pmm["ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if pmm["ms"] > 0 else 0.0,
