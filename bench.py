@@ -162,9 +162,23 @@ def main():
         model.eval()
 
     if rank == 0:
-        lin, pmm, nrm = prof["linear_gemm"], prof["plane_matmul"], prof["inorm"]
-        ach = lin["work"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
+        pmm, nrm = prof["plane_matmul"], prof["inorm"]
+        lin_keys = ("linear_gemm", "wstat_mlp2", "wstat_sum2", "wstat_cols")
+        lin = {f: sum(prof[k][f] for k in lin_keys) for f in ("ms", "work", "launches")}
+        tf = lambda c: (c["work"] / (c["ms"] * 1e-3) / 1e12) if c["ms"] > 0 else 0.0
+        # dominant kernel: the fused MLP pair when H = 128 (weight-stationary path), else the generic linear GEMM
+        dom_key = "wstat_mlp2" if prof["wstat_mlp2"]["launches"] > 0 else "linear_gemm"
+        dom = prof[dom_key]
+        dom_name = {"wstat_mlp2": "wstat_kernel<WS_MLP2,false> (both per-position MLPs of a PPGN layer, v_mfma_f32_32x32x2_f32; "
+                                  "8*H^2*P*B FLOP per launch)",
+                    "linear_gemm": "gemm_f32_kernel<...,TAG=0> (per-position linear layers, v_mfma_f32_32x32x2_f32)"}[dom_key]
         F = fwd_flops_per_graph(N, H, L)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_aggregate.py from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("geometry") == {"nodes": N, "hidden": H, "layers": L, "graphs_per_gpu": B}:
+                traffic = tj.get("bytes_per_launch", {}).get(dom_key)
         line = {
             "metric": "graphs sampled/s (PPGN, N=200); train steps/s in `train`", "value": graphs_per_s, "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -173,19 +187,25 @@ def main():
                                    f"{T} noise levels, {B} graphs/GPU per chain", "nodes": N, "hidden": H, "layers": L,
                        "noise_levels": T, "graphs_per_gpu": B, "parallelism": f"graph-sharded x{world}, no collective"},
             "model_tflops": graphs_per_s * T * F / 1e12,
-            "roofline": {"kernel": "per-position linear layers on v_mfma_f32_32x32x2_f32: wstat_kernel<MLP2|SUM2|COLS> (H=128) + gemm_f32_kernel<...,TAG=0> (in_lin, layer_cat_lin)",
-                         "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "launches": lin["launches"], "avg_launch_ms": lin["ms"] / max(lin["launches"], 1),
-                         "share_of_step_time": lin["ms"] * 1e-3 / dt, "records_truncated": truncated},
+            "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": tf(dom), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf(dom) / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                         "flops_per_launch": dom["work"] / max(dom["launches"], 1),
+                         "share_of_step_time": dom["ms"] * 1e-3 / dt, "records_truncated": truncated},
+            "roofline_linear_all": {"kernel": "every per-position linear layer (wstat MLP2 / SUM2 / COLS + generic GEMM for in_lin, layer_cat_lin)",
+                                    "bound": "mfma", "achieved": tf(lin), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf(lin) / F32_MFMA_PEAK_TFLOPS, "share_of_step_time": lin["ms"] * 1e-3 / dt,
+                                    "by_kernel": {k: {"tflops": tf(prof[k]), "launches": prof[k]["launches"],
+                                                      "avg_launch_ms": prof[k]["ms"] / max(prof[k]["launches"], 1)} for k in lin_keys}},
             "roofline_matmul": {"kernel": "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)",
-                                "bound": "mfma", "achieved": (pmm["work"] / (pmm["ms"] * 1e-3) / 1e12) if pmm["ms"] > 0 else 0.0,
-                                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": (pmm["work"] / (pmm["ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if pmm["ms"] > 0 else 0.0,
-                                "launches": pmm["launches"], "share_of_step_time": pmm["ms"] * 1e-3 / dt},
+                                "bound": "mfma", "achieved": tf(pmm), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf(pmm) / F32_MFMA_PEAK_TFLOPS,
+                                "launches": pmm["launches"], "avg_launch_ms": pmm["ms"] / max(pmm["launches"], 1),
+                                "share_of_step_time": pmm["ms"] * 1e-3 / dt},
             "roofline_inorm": {"bound": "hbm", "achieved": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9) if nrm["ms"] > 0 else 0.0,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if nrm["ms"] > 0 else 0.0,
+                               "avg_launch_ms": nrm["ms"] / max(nrm["launches"], 1),
                                "share_of_step_time": nrm["ms"] * 1e-3 / dt},
             "train": train,
         }

@@ -281,7 +281,7 @@ inline int ws_launch(int mode, bool save_hid, const WsArgs& a, hipStream_t st) {
   if (mode == WS_MLP2) rc = save_hid ? ws_launch_one<WS_MLP2, true>(a, st) : ws_launch_one<WS_MLP2, false>(a, st);
   else if (mode == WS_SUM2) rc = ws_launch_one<WS_SUM2, false>(a, st);
   else rc = ws_launch_one<WS_COLS, false>(a, st);
-  if (prof) prof_after(st, PROF_LINEAR, ws_flops(mode, a));
+  if (prof) prof_after(st, mode == WS_MLP2 ? PROF_WS_MLP2 : (mode == WS_SUM2 ? PROF_WS_SUM2 : PROF_WS_COLS), ws_flops(mode, a));
   return rc;
 }
 

@@ -322,7 +322,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
                              beta2, eps, weight_decay, int(step), grad_scale, _stream()), "dppm_adam_step")
 
 
-PROF_CLASSES = ("linear_gemm", "plane_matmul", "wgrad_gemm", "inorm")
+PROF_CLASSES = ("linear_gemm", "plane_matmul", "wgrad_gemm", "inorm", "wstat_mlp2", "wstat_sum2", "wstat_cols")
 
 
 def prof_begin(max_records=200000):

@@ -200,8 +200,9 @@ int dppm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * Measurement hooks (no counterpart in the reference; used by bench.py only).
  * dppm_prof_begin arms per-launch HIP-event timing of the GEMM-family and norm kernels (events are recorded on the
  * stream each kernel is launched on); dppm_prof_end waits for them and returns, per kernel class
- * (0 = per-position linear GEMMs, 1 = per-channel N x N contraction, 2 = weight-gradient GEMMs, 3 = instance norm),
- * the summed device time [ms], the summed algorithmic work (FLOPs for 0-2, bytes for 3) and the launch count.
+ * (0 = per-position linear layers on the generic GEMM, 1 = per-channel N x N contraction, 2 = weight-gradient GEMMs,
+ * 3 = instance norm, 4 / 5 / 6 = weight-stationary kernels: fused MLP pair / skip-concat Linear / single Linear),
+ * the summed device time [ms], the summed algorithmic work (FLOPs; bytes for 3) and the launch count (nclass >= 7).
  * Returns 1 if more than max_records launches happened (totals then cover the first max_records only).
  * Process-global, not thread-safe; arm it from one thread with no other caller active.
  * ---------------------------------------------------------------------------------------------- */
