@@ -349,15 +349,18 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
 int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long x_bs, const float* maskp, float* o1, float* o2,
              float* hid1, float* hid2, bool save_hid) {
   const long hs = (long)H * c.P;
-  if (use_wstat(H)) {   // weight-stationary fused pair: X read once, hidden activations stay in LDS unless training
+  if (use_wstat(H)) {   // weight-stationary fused pair: hidden activations stay in LDS unless training
     WsArgs wa{};
-    wa.X0 = x; wa.x0_bs = x_bs;
-    wa.W0 = q.m1_w0; wa.W1 = q.m2_w0; wa.W2 = q.m1_w1; wa.W3 = q.m2_w1; wa.ldw01 = H; wa.ldw23 = H;
-    wa.b0 = q.m1_b0; wa.b1 = q.m2_b0; wa.b2 = q.m1_b1; wa.b3 = q.m2_b1;
-    wa.maskp = maskp; wa.Y0 = o1; wa.Y1 = o2; wa.y_bs = hs;
-    wa.H0 = save_hid ? hid1 : nullptr; wa.H1 = save_hid ? hid2 : nullptr;
-    wa.B = c.B; wa.P = c.P;
-    return ws_launch(WS_MLP2, save_hid, wa, c.st);
+    wa.njobs = 2; wa.maskp = maskp; wa.B = c.B; wa.P = c.P;
+    const float* w0[2] = {q.m1_w0, q.m2_w0}; const float* w1[2] = {q.m1_w1, q.m2_w1};
+    const float* b0[2] = {q.m1_b0, q.m2_b0}; const float* b1[2] = {q.m1_b1, q.m2_b1};
+    float* out[2] = {o1, o2}; float* hid[2] = {hid1, hid2};
+    for (int k = 0; k < 2; ++k) {
+      WsJob& j = wa.job[k];
+      j.X = x; j.x_bs = x_bs; j.W1 = w0[k]; j.W2 = w1[k]; j.ldw1 = H; j.ldw2 = H; j.b1 = b0[k]; j.b2 = b1[k];
+      j.Mid = save_hid ? hid[k] : nullptr; j.mid_bs = hs; j.Y = out[k]; j.y_bs = hs;
+    }
+    return ws_mlp_forward(wa, save_hid, c.st);
   }
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, false, hid1, hs, H}, nullptr, q.m1_b1, 0, maskp, nullptr, 0, o1, hs, false));
@@ -539,10 +542,11 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
     if (use_wstat(H)) {
       WsArgs wa{};
-      wa.X0 = mm; wa.x0_bs = hs; wa.X1 = x; wa.x1_bs = x_bs;
-      wa.W0 = q.m4_w; wa.W1 = q.m4_w + H; wa.ldw01 = 2 * H; wa.b0 = q.m4_b;
-      wa.Y0 = y; wa.y_bs = hs; wa.B = B; wa.P = P;
-      DPPM_TRY(ws_launch(WS_SUM2, false, wa, c.st));
+      wa.njobs = 1; wa.B = B; wa.P = P;
+      WsJob& j = wa.job[0];
+      j.X = mm; j.x_bs = hs; j.X2 = x; j.x2_bs = x_bs; j.W1 = q.m4_w; j.W2 = q.m4_w + H; j.ldw1 = 2 * H; j.ldw2 = 2 * H; j.b1 = q.m4_b;
+      j.Y = y; j.y_bs = hs;
+      DPPM_TRY(ws_lin(wa, 2, false, c.st));
     } else {
       LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
@@ -559,9 +563,10 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   // out + LeakyReLU(after_conv(out)) ; final_lin   (model/ppgn.py:331-333)
   if (use_wstat(H)) {
     WsArgs wa{};
-    wa.X0 = c.at(w.R); wa.x0_bs = hs; wa.W0 = pr->after_w; wa.ldw01 = H; wa.b0 = pr->after_b; wa.act = 1;
-    wa.Y0 = c.at(w.act); wa.y_bs = hs; wa.B = B; wa.P = P;
-    DPPM_TRY(ws_launch(WS_COLS, false, wa, c.st));
+    wa.njobs = 1; wa.B = B; wa.P = P; wa.act = 1;
+    WsJob& j = wa.job[0];
+    j.X = c.at(w.R); j.x_bs = hs; j.W1 = pr->after_w; j.ldw1 = H; j.b1 = pr->after_b; j.Y = c.at(w.act); j.y_bs = hs;
+    DPPM_TRY(ws_lin(wa, 1, false, c.st));
   } else {
     DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, false, c.at(w.R), hs, H}, nullptr, pr->after_b, 1, nullptr, nullptr, 0, c.at(w.act), hs, false));
   }
@@ -609,10 +614,32 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
   DPPM_TRY(check_launch("reduce(dbfin)"));
   DPPM_TRY(wgrad(c, H, dz, hs, H, c.at(w.R), hs, gr->after_w, H, gr->after_b));
   // dR = dh + W_ac^T dz   (accumulated into dh)
-  DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, true, dz, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dh, hs, true));
+  const bool ws = use_wstat(H);
+  if (ws) {
+    WsArgs wa{};
+    wa.njobs = 1; wa.B = B; wa.P = P;
+    WsJob& j = wa.job[0];
+    j.X = dz; j.x_bs = hs; j.W1 = pr->after_w; j.ldw1 = H; j.Y = dh; j.y_bs = hs; j.accumulate = 1;
+    DPPM_TRY(ws_lin(wa, 1, true, c.st));
+  } else {
+    DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, true, dz, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dh, hs, true));
+  }
   // layer_cat_lin
   DPPM_TRY(wgrad(c, H, dh, hs, w.CT, cat, cat_bs, gr->cat_w, w.CT, gr->cat_b));
-  DPPM_TRY(linear(c, w.CT, LinArgs{pr->cat_w, w.CT, true, dh, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dcat, cat_bs, false));
+  if (ws) {   // d u_j = W_cat[:, 2 + jH ..]^T dh, one job per layer output (rows 0, 1 of dcat - the inputs - have no consumer)
+    for (int j0 = 0; j0 < L; j0 += WS_MAX_JOBS) {
+      WsArgs wa{};
+      wa.njobs = L - j0 < WS_MAX_JOBS ? L - j0 : WS_MAX_JOBS; wa.B = B; wa.P = P;
+      for (int k = 0; k < wa.njobs; ++k) {
+        WsJob& j = wa.job[k];
+        j.X = dh; j.x_bs = hs; j.W1 = pr->cat_w + 2 + (size_t)(j0 + k) * H; j.ldw1 = w.CT;
+        j.Y = dcat + (size_t)(2 + (j0 + k) * H) * P; j.y_bs = cat_bs;
+      }
+      DPPM_TRY(ws_lin(wa, 1, true, c.st));
+    }
+  } else {
+    DPPM_TRY(linear(c, w.CT, LinArgs{pr->cat_w, w.CT, true, dh, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dcat, cat_bs, false));
+  }
 
   for (int l = L - 1; l >= 0; --l) {
     const dppm_ppgn_layer& q = pr->layers_host[l];
@@ -633,22 +660,42 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     // m4
     DPPM_TRY(wgrad(c, H, dy, hs, H, mm, hs, gq.m4_w, 2 * H, gq.m4_b));
     DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gq.m4_w + H, 2 * H, nullptr));
-    DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dmm, hs, false));
-    DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));
+    if (ws) {
+      WsArgs wa{};
+      wa.njobs = 2; wa.B = B; wa.P = P;
+      WsJob& j0 = wa.job[0];
+      j0.X = dy; j0.x_bs = hs; j0.W1 = q.m4_w; j0.ldw1 = 2 * H; j0.Y = dmm; j0.y_bs = hs;
+      WsJob& j1 = wa.job[1];
+      j1.X = dy; j1.x_bs = hs; j1.W1 = q.m4_w + H; j1.ldw1 = 2 * H; j1.Y = dx; j1.y_bs = dx_bs; j1.accumulate = l != 0;
+      DPPM_TRY(ws_lin(wa, 1, true, c.st));
+    } else {
+      DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dmm, hs, false));
+      DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));
+    }
     // contraction: do1 = dmm o2^T / sqrt(n) * mask ; do2 = o1^T dmm / sqrt(n) * mask
     DPPM_TRY(plane_mm(c.st, dmm, o2, do1, B * H, N, w.ld, false, true, c.at(w.inv_norm), maskp, H));
     DPPM_TRY(plane_mm(c.st, o1, dmm, do2, B * H, N, w.ld, true, false, c.at(w.inv_norm), maskp, H));
     // m1 (dy is free again: reuse it for the pre-activation gradient)
     float* dpre = dy;
-    DPPM_TRY(wgrad(c, H, do1, hs, H, hid1, hs, gq.m1_w1, H, gq.m1_b1));
-    DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, true, do1, hs, H}, nullptr, nullptr, 0, nullptr, hid1, hs, dpre, hs, false));
-    DPPM_TRY(wgrad(c, H, dpre, hs, H, x, x_bs, gq.m1_w0, H, gq.m1_b0));
-    DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, true, dpre, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, true));
-    // m2
-    DPPM_TRY(wgrad(c, H, do2, hs, H, hid2, hs, gq.m2_w1, H, gq.m2_b1));
-    DPPM_TRY(linear(c, H, LinArgs{q.m2_w1, H, true, do2, hs, H}, nullptr, nullptr, 0, nullptr, hid2, hs, dpre, hs, false));
-    DPPM_TRY(wgrad(c, H, dpre, hs, H, x, x_bs, gq.m2_w0, H, gq.m2_b0));
-    DPPM_TRY(linear(c, H, LinArgs{q.m2_w0, H, true, dpre, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, true));
+    const float* dout[2] = {do1, do2}; const float* hid[2] = {hid1, hid2};
+    const float* wl0[2] = {q.m1_w0, q.m2_w0}; const float* wl1[2] = {q.m1_w1, q.m2_w1};
+    float* gw0[2] = {gq.m1_w0, gq.m2_w0}; float* gb0[2] = {gq.m1_b0, gq.m2_b0};
+    float* gw1[2] = {gq.m1_w1, gq.m2_w1}; float* gb1[2] = {gq.m1_b1, gq.m2_b1};
+    for (int k = 0; k < 2; ++k) {
+      DPPM_TRY(wgrad(c, H, dout[k], hs, H, hid[k], hs, gw1[k], H, gb1[k]));
+      if (ws) {   // dpre = (W1^T dout) * act'(hid) ; dx += W0^T dpre, the intermediate never leaves the CU except as the saved copy
+        WsArgs wa{};
+        wa.njobs = 1; wa.B = B; wa.P = P;
+        WsJob& j = wa.job[0];
+        j.X = dout[k]; j.x_bs = hs; j.W1 = wl1[k]; j.ldw1 = H; j.W2 = wl0[k]; j.ldw2 = H; j.Hsaved = hid[k]; j.hs_bs = hs;
+        j.Mid = dpre; j.mid_bs = hs; j.Y = dx; j.y_bs = dx_bs; j.accumulate = 1;
+        DPPM_TRY(ws_mlp_backward(wa, c.st));
+      } else {
+        DPPM_TRY(linear(c, H, LinArgs{wl1[k], H, true, dout[k], hs, H}, nullptr, nullptr, 0, nullptr, hid[k], hs, dpre, hs, false));
+      }
+      DPPM_TRY(wgrad(c, H, dpre, hs, H, x, x_bs, gw0[k], H, gb0[k]));
+      if (!ws) DPPM_TRY(linear(c, H, LinArgs{wl0[k], H, true, dpre, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, true));
+    }
   }
   // in_lin
   DPPM_TRY(wgrad(c, H, du0, hs, 2, cat, cat_bs, gr->in_w, 2, gr->in_b));

@@ -2,286 +2,371 @@
 // 12 N^2 H^2 + 2 H N^3).  In channel-first layout a Linear is Y (128 x P) = W (128 x 128) * X (128 x P) with P = N*ld
 // positions per graph: a tall-skinny problem whose only large dimension is P.  So the weights stay put and the
 // positions stream through:
-//   - a persistent workgroup (8 wave64, one per CU, 256 of them) walks 64-position tiles of all graphs;
-//   - each wave keeps its 32 x 128 weight slice(s) in 64 VGPRs per matrix for the whole launch (loaded once);
-//   - the X tile (128 channels x 64 positions, 32 KB) is staged through LDS, double buffered, the next tile's
-//     global loads being issued before the current tile's MFMAs; all waves read it as the MFMA B operand with
-//     conflict-free ds_read_b32;
-//   - v_mfma_f32_32x32x2_f32 does the arithmetic (exact f32).  The k order inside a step is chosen as
-//     k = ks + 64 * (lane >> 5) so that a lane's 64 weight values are one contiguous run of its row.
-// Modes
-//   MLP2 : waves 0-3 compute m1, waves 4-7 compute m2 (model/ppgn.py:58-59): hid = LeakyReLU(Wa X + ba) goes to LDS
-//          (never to HBM in inference), then out = (Wb hid + bb) * mask.  One read of X, two writes.
-//   SUM2 : Y = Wp * Xp + Wq * Xq + b, the skip-concat Linear m4 (model/ppgn.py:66-69) without materialising the cat:
-//          every wave holds both 32 x 128 weight slices and runs one 256-deep chain; the wave groups split the columns.
-//   COLS : Y = epilogue(W X + b) for one source, the two wave groups splitting a 128-position tile (after_conv).
+//   - persistent workgroups of 8 wave64, TWO per CU (independent barriers: one group's epilogue and staging overlap
+//     the other's MFMAs), walk 64-position tiles of all graphs;
+//   - wave w keeps the weights of output channels 16w .. 16w+15 in 32 VGPRs per matrix for the whole launch;
+//   - the X tile (128 channels x 64 positions, 32 KB) is staged through LDS (global -> registers while the previous
+//     tile computes -> LDS) and read by every wave as the MFMA A operand with conflict-free ds_read_b32;
+//   - v_mfma_f32_16x16x4_f32 computes D[position][channel] (exact f32), i.e. the transposed tile, so a lane ends up with
+//     four CONSECUTIVE positions of one channel: every store is a 16-byte store.  The k order inside the chain is
+//     k = 32 * (lane >> 4) + step so that a lane's 32 weights are one contiguous run of its row.
+// Kernels
+//   ws_mlp_kernel : Linear -> elementwise -> Linear with the intermediate in LDS.
+//                   forward  (model/ppgn.py:58-59):  out = (W2 LeakyReLU(W1 X + b1) + b2) * mask         [hid saved for training]
+//                   backward:                         dpre = (W1^T dOut) * LeakyReLU'(hid) [saved for the weight gradients],
+//                                                     dX (+)= W2^T dpre      (W1 = the MLP's second matrix, W2 = its first)
+//   ws_lin_kernel : Y (+)= epilogue(sum_s W_s X_s + b), one or two 128-channel sources (the skip-concat Linear m4 of
+//                   model/ppgn.py:66-69 without materialising the cat; after_conv; every transposed data-gradient form).
+// A launch carries up to 8 independent jobs (weights / sources / outputs); a workgroup serves one job for its lifetime
+// and jobs that read the same source sit on the same XCD so the second read of a tile is an L2 hit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dppm_gemm.h"
 
 namespace dppm {
 
-constexpr int WS_H = 128;        // channels handled by these kernels
-constexpr int WS_BP = 64;        // positions per tile and wave group
-constexpr int WS_THREADS = 512;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-enum WsMode { WS_MLP2 = 0, WS_SUM2 = 1, WS_COLS = 2 };
+constexpr int WS_H = 128;          // channels handled by these kernels
+constexpr int WS_TP = 64;          // positions per tile
+constexpr int WS_THREADS = 512;
+constexpr int WS_XP = 64;          // LDS row pitch of a staged source tile (floats)
+constexpr int WS_HP = 68;          // LDS row pitch of the intermediate tile (16-byte writes from 16 rows at once stay conflict-free)
+constexpr int WS_XS = WS_H * WS_XP + 64;   // floats per staged tile incl. the 16-float skew per 32 rows
+constexpr int WS_HS = WS_H * WS_HP + 64;
+constexpr int WS_MAX_JOBS = 8;
+constexpr int WS_WG_PER_XCD = 64;  // 32 CUs x 2 resident workgroups
+
+struct WsJob {
+  const float* X;  long x_bs;      // source planes [B][128][P]
+  const float* X2; long x2_bs;     // ws_lin with two sources: the second one
+  const float* W1; const float* W2;   // mlp: first / second stage matrix;  lin: matrix of source 1 / source 2
+  int ldw1, ldw2;
+  const float* b1; const float* b2;   // mlp: stage biases; lin: b1 only (nullable)
+  const float* Hsaved; long hs_bs;    // mlp backward: the saved hidden activations
+  float* Mid; long mid_bs;            // mlp: where the intermediate is saved (SAVE_MID)
+  float* Y; long y_bs;
+  int accumulate;                     // Y += result
+};
 
 struct WsArgs {
-  // sources: MLP2 uses X0 only; SUM2 uses X0 (with W0) and X1 (with W1); COLS uses X0
-  const float* X0; long x0_bs;
-  const float* X1; long x1_bs;
-  // weights, torch [out][in] layout, row pitch ldw
-  const float* W0; const float* W1;     // MLP2: first layers of m1 / m2;   SUM2: the two column blocks of m4;  COLS: W0
-  const float* W2; const float* W3;     // MLP2: second layers of m1 / m2
-  int ldw01, ldw23;
-  const float* b0; const float* b1; const float* b2; const float* b3;   // biases matching W0..W3 (SUM2: b0 only)
-  const float* maskp;                   // [B][P] or null (MLP2: applied to both outputs)
-  int act;                              // COLS: LeakyReLU on the output
-  float* Y0; float* Y1; long y_bs;      // MLP2: o1, o2;  SUM2 / COLS: Y0
-  float* H0; float* H1;                 // MLP2 training: hidden activations saved for backward (else null)
+  WsJob job[WS_MAX_JOBS];
+  int njobs;
+  const float* maskp;                 // [B][P] or null: multiplies the result
+  int act;                            // lin: LeakyReLU on the result
   int B, P;
 };
 
-__device__ __forceinline__ int ws_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int ws_hoff(int k) { return k * WS_HP + 16 * (k >> 5); }
 
-// one wave's 32 x 128 slice of W (rows row0..row0+31) into 64 registers: w[ks] = W[row0 + (lane&31)][64*(lane>>5) + ks]
-__device__ __forceinline__ void ws_load_weights(float (&w)[64], const float* __restrict__ W, int ldw, int row0, int lane) {
-  const float* p = W + (size_t)(row0 + (lane & 31)) * ldw + 64 * (lane >> 5);
-  if ((ldw & 3) == 0 && (((uintptr_t)W) & 15) == 0) {
+// a lane's 32 weights of output channel ch: w[s] = W[ch][32 g + s]   (TRANS: W^T, i.e. w[s] = W[32 g + s][ch])
+template <bool TRANS>
+__device__ __forceinline__ void ws_load_w(float (&w)[32], const float* __restrict__ W, int ldw, int ch, int g) {
+  if (TRANS) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const float4 q = reinterpret_cast<const float4*>(p)[v];
-      w[4 * v + 0] = q.x; w[4 * v + 1] = q.y; w[4 * v + 2] = q.z; w[4 * v + 3] = q.w;
-    }
+    for (int s = 0; s < 32; ++s) w[s] = W[(size_t)(32 * g + s) * ldw + ch];
   } else {
+    const float* p = W + (size_t)ch * ldw + 32 * g;
+    if ((((uintptr_t)p) & 15) == 0) {
 #pragma unroll
-    for (int k = 0; k < 64; ++k) w[k] = p[k];
+      for (int v = 0; v < 8; ++v) {
+        const float4 q = reinterpret_cast<const float4*>(p)[v];
+        w[4 * v + 0] = q.x; w[4 * v + 1] = q.y; w[4 * v + 2] = q.z; w[4 * v + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) w[s] = p[s];
+    }
   }
 }
 
-// acc (32 rows x 64 cols, two MFMA tiles) += Wslice * T, T an LDS tile [128][WS_BP]
-__device__ __forceinline__ void ws_mma(floatx16& a0, floatx16& a1, const float (&w)[64], const float* __restrict__ T, int lane) {
-  const float* t = T + (64 * (lane >> 5)) * WS_BP + (lane & 31);
+// acc[j] (16 positions x 16 channels, j = 0..3) += T[:, 16 j ..]^T * Wslice^T ; T points at the lane's first element
+template <int PITCH>
+__device__ __forceinline__ void ws_mma4(floatx4 (&acc)[4], const float (&w)[32], const float* __restrict__ T) {
 #pragma unroll
-  for (int ks = 0; ks < 64; ++ks) {
-    const float b0 = t[ks * WS_BP], b1 = t[ks * WS_BP + 32];
-    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], b0, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], b1, a1, 0, 0, 0);
+  for (int s = 0; s < 32; ++s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[s * PITCH + 16 * j], w[s], acc[j], 0, 0, 0);
   }
 }
 
-// single-tile form: acc (32 x 32) += Wslice * T[:, col0 .. col0+31]  (T already offset to col0)
-__device__ __forceinline__ void ws_mma1(floatx16& a0, const float (&w)[64], const float* __restrict__ T, int lane) {
-  const float* t = T + (64 * (lane >> 5)) * WS_BP + (lane & 31);
-#pragma unroll
-  for (int ks = 0; ks < 64; ++ks) a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ks], t[ks * WS_BP], a0, 0, 0, 0);
-}
-
-// global tile (128 rows x 64 positions at p0) -> registers (4 float4 per thread of the 512) / registers -> LDS
-__device__ __forceinline__ void ws_tile_load(float4 (&r)[4], const float* __restrict__ X, int P, int p0, int tid) {
+// global tile (128 rows x 64 positions) -> registers (4 float4 per thread) / registers -> LDS.
+// Xt: uniform pointer to (row 0, first position of the tile); o0 = (tid >> 4) * P + 4 * (tid & 15); ok: the lane's four
+// positions lie inside the plane.  Uniform base + 32-bit lane offset keeps the address math off the vector registers.
+__device__ __forceinline__ void ws_tile_load(float4 (&r)[4], const float* __restrict__ Xt, unsigned P, unsigned o0, bool ok) {
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    const int idx = tid + v * WS_THREADS;
-    const int k = idx >> 4, c = (idx & 15) * 4;
-    r[v] = (p0 + c < P) ? *reinterpret_cast<const float4*>(X + (size_t)k * P + p0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Xv = Xt + (size_t)(32 * v) * P;
+    r[v] = ok ? *reinterpret_cast<const float4*>(Xv + o0) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 __device__ __forceinline__ void ws_tile_store(const float4 (&r)[4], float* __restrict__ T, int tid) {
+  float* q = T + (tid >> 4) * WS_XP + (tid & 15) * 4;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int idx = tid + v * WS_THREADS;
-    *reinterpret_cast<float4*>(T + (idx >> 4) * WS_BP + (idx & 15) * 4) = r[v];
+  for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(q + 32 * v * WS_XP + 16 * v) = r[v];   // row (tid >> 4) + 32 v, skew 16 v
+}
+
+struct WsWho { int jid, rank, per_job; };
+__device__ __forceinline__ WsWho ws_who(int njobs) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  WsWho w;
+  w.jid = __builtin_amdgcn_readfirstlane(slot % njobs);
+  w.rank = __builtin_amdgcn_readfirstlane((slot / njobs) * 8 + xcd);
+  w.per_job = __builtin_amdgcn_readfirstlane((int)(gridDim.x >> 3) / njobs * 8);
+  return w;
+}
+
+__device__ __forceinline__ float ws_leaky(float v) { return v > 0.f ? v : kSlope * v; }
+__device__ __forceinline__ float4 ws_f4(const floatx4& a) { return make_float4(a[0], a[1], a[2], a[3]); }
+
+// result tile -> global: optional LeakyReLU, mask, accumulate.  Yt / Mt: uniform pointers to the tile's first position;
+// r0 = ch * P + 4 g, m0 = 4 g: the lane's offsets; lim = positions left in the plane from the tile's start.
+__device__ __forceinline__ void ws_store_out(const floatx4 (&acc)[4], float* __restrict__ Yt, unsigned r0, const float* __restrict__ Mt,
+                                             unsigned m0, int lim, float bias, bool act, bool accumulate) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if ((int)m0 + 16 * j < lim) {
+      float4 v = ws_f4(acc[j]);
+      v.x += bias; v.y += bias; v.z += bias; v.w += bias;   // after the chain, as a GEMM epilogue would: one rounding at the bias' magnitude
+      if (act) { v.x = ws_leaky(v.x); v.y = ws_leaky(v.y); v.z = ws_leaky(v.z); v.w = ws_leaky(v.w); }
+      if (Mt) {
+        const float4 m = *reinterpret_cast<const float4*>(Mt + m0 + 16 * j);
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+      }
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(Yt + r0 + 16 * j);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(Yt + r0 + 16 * j) = v;
+    }
   }
 }
 
-template <int MODE, bool SAVE_HID>
-__global__ __launch_bounds__(WS_THREADS, 2) void wstat_kernel(const WsArgs a) {
+template <bool BWD, bool TRANS, bool SAVE_MID>
+__global__ __launch_bounds__(WS_THREADS, 4) void ws_mlp_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int TILE = WS_H * WS_BP;                 // floats in one staged tile (32 KB)
-  // LDS carve:  MLP2: X[2 stages], Hid[2 groups] ; SUM2: [2 stages][Xp, Xq] ; COLS: [2 stages][2 column halves] ; biases
   float* Xs = smem;
-  float* Hs = smem + 2 * TILE;                       // MLP2 only
-  float* Bs = smem + 4 * TILE;                       // biases [4][128]
-
+  float* Hs = smem + WS_XS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave >> 2, rg = wave & 3;            // wave group (0/1), row group (32 output rows each)
-  const int P = a.P;
-  const int tiles_per_plane = (P + (MODE == WS_COLS ? 2 * WS_BP : WS_BP) - 1) / (MODE == WS_COLS ? 2 * WS_BP : WS_BP);
-  const int ntiles = a.B * tiles_per_plane;
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * wave + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
 
-  // ---- one-time: weights to registers, biases to LDS
-  float wA[64], wB[64];
-  if (MODE == WS_MLP2) {
-    ws_load_weights(wA, g == 0 ? a.W0 : a.W1, a.ldw01, 32 * rg, lane);
-    ws_load_weights(wB, g == 0 ? a.W2 : a.W3, a.ldw23, 32 * rg, lane);
-  } else if (MODE == WS_SUM2) {
-    ws_load_weights(wA, a.W0, a.ldw01, 32 * rg, lane);
-    ws_load_weights(wB, a.W1, a.ldw01, 32 * rg, lane);
-  } else {
-    ws_load_weights(wA, a.W0, a.ldw01, 32 * rg, lane);
-  }
-  if (tid < WS_H) {
-    Bs[tid] = a.b0 ? a.b0[tid] : 0.f;
-    Bs[WS_H + tid] = (MODE == WS_MLP2 && a.b1) ? a.b1[tid] : 0.f;
-    Bs[2 * WS_H + tid] = (MODE == WS_MLP2 && a.b2) ? a.b2[tid] : 0.f;
-    Bs[3 * WS_H + tid] = (MODE == WS_MLP2 && a.b3) ? a.b3[tid] : 0.f;
-  }
+  float w1[32], w2[32];
+  ws_load_w<TRANS>(w1, J.W1, J.ldw1, ch, g);
+  ws_load_w<TRANS>(w2, J.W2, J.ldw2, ch, g);
+  const float b1v = J.b1 ? J.b1[ch] : 0.f, b2v = J.b2 ? J.b2[ch] : 0.f;
 
-  auto tile_src = [&](int t, int which, const float*& X, int& p0) {   // which: 0 -> X0, 1 -> X1 (SUM2) / second half (COLS)
-    const int b = t / tiles_per_plane, tp = t % tiles_per_plane;
-    if (MODE == WS_COLS) { X = a.X0 + (size_t)b * a.x0_bs; p0 = tp * 2 * WS_BP + which * WS_BP; }
-    else if (which == 0) { X = a.X0 + (size_t)b * a.x0_bs; p0 = tp * WS_BP; }
-    else { X = a.X1 + (size_t)b * a.x1_bs; p0 = tp * WS_BP; }
-  };
-  constexpr int NSRC = (MODE == WS_MLP2) ? 1 : 2;    // staged tiles per step
+  const unsigned o0 = (unsigned)(tid >> 4) * P + 4 * (tid & 15);   // staging: row tid >> 4, 4 positions
+  const int oc = 4 * (tid & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;                    // results: row ch, positions 16 j + 4 g ..
+  const unsigned m0 = 4 * g;
 
-  float4 pre[NSRC][4];
-  int t = blockIdx.x;
+  float4 pre[4];
+  int t = who.rank;
   if (t < ntiles) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    ws_tile_load(pre, J.X + (size_t)b * J.x_bs + p0, P, o0, p0 + oc < P);
+    ws_tile_store(pre, Xs, tid);
+  }
+  __syncthreads();
+
+  const float* xa = Xs + (32 * g) * WS_XP + 16 * g + ci;   // lane's A-operand base: row 32 g, position ci
+  const float* ha = Hs + (32 * g) * WS_HP + 16 * g + ci;
+  float* hw = Hs + ws_hoff(ch) + 4 * g;                    // lane's intermediate slot: row ch, positions 16 j + 4 g ..
+
+  for (; t < ntiles; t += who.per_job) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const int tn = t + who.per_job;
+    const int lim = P - p0;
+    float4 hs[4];
+    if (BWD) {
+      const float* Ht = J.Hsaved + (size_t)b * J.hs_bs + p0;
 #pragma unroll
-    for (int s = 0; s < NSRC; ++s) {
-      const float* X; int p0;
-      tile_src(t, s, X, p0);
-      ws_tile_load(pre[s], X, P, p0, tid);
-      ws_tile_store(pre[s], Xs + s * TILE, tid);       // stage 0
+      for (int j = 0; j < 4; ++j)
+        hs[j] = ((int)m0 + 16 * j < lim) ? *reinterpret_cast<const float4*>(Ht + r0 + 16 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ws_mma4<WS_XP>(acc, w1, xa);
+    // ---- elementwise stage; intermediate to LDS (and to HBM when a later pass needs it)
+    float* Mt = SAVE_MID ? J.Mid + (size_t)b * J.mid_bs + p0 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v;
+      if (BWD) {
+        v.x = acc[j][0] * (hs[j].x > 0.f ? 1.f : kSlope); v.y = acc[j][1] * (hs[j].y > 0.f ? 1.f : kSlope);
+        v.z = acc[j][2] * (hs[j].z > 0.f ? 1.f : kSlope); v.w = acc[j][3] * (hs[j].w > 0.f ? 1.f : kSlope);
+      } else {
+        v.x = ws_leaky(acc[j][0] + b1v); v.y = ws_leaky(acc[j][1] + b1v); v.z = ws_leaky(acc[j][2] + b1v); v.w = ws_leaky(acc[j][3] + b1v);
+      }
+      *reinterpret_cast<float4*>(hw + 16 * j) = v;
+      if (SAVE_MID) {
+        if ((int)m0 + 16 * j < lim) *reinterpret_cast<float4*>(Mt + r0 + 16 * j) = v;
+      }
+    }
+    __syncthreads();
+    if (tn < ntiles) {   // next tile: in flight during stage 2
+      const int bn = __builtin_amdgcn_readfirstlane(tn / tpp), pn = __builtin_amdgcn_readfirstlane((tn % tpp) * WS_TP);
+      ws_tile_load(pre, J.X + (size_t)bn * J.x_bs + pn, P, o0, pn + oc < P);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ws_mma4<WS_HP>(acc, w2, ha);
+    if (tn < ntiles) ws_tile_store(pre, Xs, tid);          // every wave left stage 1 (the only reader of Xs) at the barrier above
+    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, lim, b2v, false,
+                 J.accumulate != 0);
+    __syncthreads();
+  }
+}
+
+template <int NSRC, bool TRANS>
+__global__ __launch_bounds__(WS_THREADS, 4) void ws_lin_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * wave + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+
+  float w[NSRC][32];
+  ws_load_w<TRANS>(w[0], J.W1, J.ldw1, ch, g);
+  if (NSRC == 2) ws_load_w<TRANS>(w[NSRC - 1], J.W2, J.ldw2, ch, g);
+  const float bv = J.b1 ? J.b1[ch] : 0.f;
+
+  const unsigned o0 = (unsigned)(tid >> 4) * P + 4 * (tid & 15);
+  const int oc = 4 * (tid & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+
+  float4 pre[4];
+  int t = who.rank;
+  if (t < ntiles) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    ws_tile_load(pre, J.X + (size_t)b * J.x_bs + p0, P, o0, p0 + oc < P);
+    ws_tile_store(pre, smem, tid);
   }
   __syncthreads();
 
   int cur = 0;
-  for (; t < ntiles; t += gridDim.x) {
-    const int tn = t + gridDim.x;
-    if (tn < ntiles) {
+  const int lane_off = (32 * g) * WS_XP + 16 * g + ci;
+  for (; t < ntiles; t += who.per_job) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const int tn = t + who.per_job;
+    floatx4 acc[4];
 #pragma unroll
-      for (int s = 0; s < NSRC; ++s) {
-        const float* X; int p0;
-        tile_src(tn, s, X, p0);
-        ws_tile_load(pre[s], X, P, p0, tid);          // in flight during the MFMAs below
-      }
-    }
-    const int b = t / tiles_per_plane, tp = t % tiles_per_plane;
-    const float* Xcur = Xs + cur * NSRC * TILE;
-    const int c = lane & 31;
-
-    floatx16 acc0, acc1;
-    if (MODE == WS_MLP2) {
-      const int p0 = tp * WS_BP;
-      // ---- stage 1: hid = LeakyReLU(Wa X + ba)
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = Bs[g * WS_H + 32 * rg + ws_row(r, lane)];
-      ws_mma(acc0, acc1, wA, Xcur, lane);
-      float* Hg = Hs + g * TILE;
-      float* Hglob = SAVE_HID ? (g == 0 ? a.H0 : a.H1) + (size_t)b * a.y_bs : nullptr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * rg + ws_row(r, lane);
-        float h0 = acc0[r], h1 = acc1[r];
-        h0 = h0 > 0.f ? h0 : kSlope * h0;
-        h1 = h1 > 0.f ? h1 : kSlope * h1;
-        Hg[row * WS_BP + c] = h0;
-        Hg[row * WS_BP + c + 32] = h1;
-        if (SAVE_HID) {
-          if (p0 + c < P) Hglob[(size_t)row * P + p0 + c] = h0;
-          if (p0 + c + 32 < P) Hglob[(size_t)row * P + p0 + c + 32] = h1;
+    for (int s = 0; s < NSRC; ++s) {
+      // the tile that follows this one in the stream: the next source of the same positions, or source 0 of the next tile
+      const bool last = (s == NSRC - 1);
+      const bool more = last ? (tn < ntiles) : true;
+      if (more) {
+        if (last) {
+          const int bn = __builtin_amdgcn_readfirstlane(tn / tpp), pn = __builtin_amdgcn_readfirstlane((tn % tpp) * WS_TP);
+          ws_tile_load(pre, J.X + (size_t)bn * J.x_bs + pn, P, o0, pn + oc < P);
+        } else {
+          ws_tile_load(pre, J.X2 + (size_t)b * J.x2_bs + p0, P, o0, p0 + oc < P);
         }
       }
+      ws_mma4<WS_XP>(acc, w[s], smem + cur * WS_XS + lane_off);
+      if (more) ws_tile_store(pre, smem + (cur ^ 1) * WS_XS, tid);
+      if (last)
+        ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
+                     J.accumulate != 0);
       __syncthreads();
-      // ---- stage 2: out = (Wb hid + bb) * mask
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = Bs[(2 + g) * WS_H + 32 * rg + ws_row(r, lane)];
-      ws_mma(acc0, acc1, wB, Hg, lane);
-      float m0 = 1.f, m1 = 1.f;
-      if (a.maskp) {
-        m0 = (p0 + c < P) ? a.maskp[(size_t)b * P + p0 + c] : 0.f;
-        m1 = (p0 + c + 32 < P) ? a.maskp[(size_t)b * P + p0 + c + 32] : 0.f;
-      }
-      float* Y = (g == 0 ? a.Y0 : a.Y1) + (size_t)b * a.y_bs;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * rg + ws_row(r, lane);
-        if (p0 + c < P) Y[(size_t)row * P + p0 + c] = acc0[r] * m0;
-        if (p0 + c + 32 < P) Y[(size_t)row * P + p0 + c + 32] = acc1[r] * m1;
-      }
-    } else if (MODE == WS_SUM2) {
-      const int p0 = tp * WS_BP + 32 * g;            // this wave group's 32 columns of the 64-position tile
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = Bs[32 * rg + ws_row(r, lane)];
-      ws_mma1(acc0, wA, Xcur + 32 * g, lane);
-      ws_mma1(acc0, wB, Xcur + TILE + 32 * g, lane);
-      float* Y = a.Y0 + (size_t)b * a.y_bs;
-      if (p0 + c < P) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Y[(size_t)(32 * rg + ws_row(r, lane)) * P + p0 + c] = acc0[r];
-      }
-    } else {   // WS_COLS
-      const int p0 = tp * 2 * WS_BP + g * WS_BP;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = Bs[32 * rg + ws_row(r, lane)];
-      ws_mma(acc0, acc1, wA, Xcur + g * TILE, lane);
-      float m0 = 1.f, m1 = 1.f;
-      if (a.maskp) {
-        m0 = (p0 + c < P) ? a.maskp[(size_t)b * P + p0 + c] : 0.f;
-        m1 = (p0 + c + 32 < P) ? a.maskp[(size_t)b * P + p0 + c + 32] : 0.f;
-      }
-      float* Y = a.Y0 + (size_t)b * a.y_bs;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * rg + ws_row(r, lane);
-        float v0 = acc0[r], v1 = acc1[r];
-        if (a.act) { v0 = v0 > 0.f ? v0 : kSlope * v0; v1 = v1 > 0.f ? v1 : kSlope * v1; }
-        if (p0 + c < P) Y[(size_t)row * P + p0 + c] = v0 * m0;
-        if (p0 + c + 32 < P) Y[(size_t)row * P + p0 + c + 32] = v1 * m1;
-      }
+      cur ^= 1;
     }
-    // ---- stage the prefetched tile(s) for the next step
-    if (tn < ntiles) {
-#pragma unroll
-      for (int s = 0; s < NSRC; ++s) ws_tile_store(pre[s], Xs + ((cur ^ 1) * NSRC + s) * TILE, tid);
-    }
-    __syncthreads();
-    cur ^= 1;
   }
 }
 
-inline size_t ws_lds_bytes(int mode) {
-  const size_t tile = (size_t)WS_H * WS_BP * sizeof(float);
-  (void)mode;
-  return 4 * tile + 4 * WS_H * sizeof(float);
+inline size_t ws_mlp_lds() { return (size_t)(WS_XS + WS_HS) * sizeof(float); }
+inline size_t ws_lin_lds() { return (size_t)(2 * WS_XS) * sizeof(float); }
+
+inline int ws_grid(int njobs, long ntiles) {
+  long slots = WS_WG_PER_XCD / njobs;                 // workgroups per job and XCD
+  const long need = (ntiles + 7) / 8;
+  if (slots > need) slots = need;
+  if (slots < 1) slots = 1;
+  return (int)(8 * njobs * slots);
 }
 
-template <int MODE, bool SAVE_HID>
-inline int ws_launch_one(const WsArgs& a, hipStream_t st) {
-  static bool attr_set = false;
-  const size_t lds = ws_lds_bytes(MODE);
+template <typename K>
+inline int ws_launch_kernel(K kernel, size_t lds, const WsArgs& a, hipStream_t st, bool& attr_set, const char* what) {
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wstat_kernel<MODE, SAVE_HID>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "wstat: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "%s: cannot raise the dynamic LDS limit to %zu bytes", what, lds);
     attr_set = true;
   }
-  const int per = (MODE == WS_COLS) ? 2 * WS_BP : WS_BP;
-  const long ntiles = (long)a.B * ((a.P + per - 1) / per);
-  const int grid = (int)(ntiles < 256 ? ntiles : 256);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(wstat_kernel<MODE, SAVE_HID>), dim3(grid), dim3(WS_THREADS), lds, st, a);
-  return check_launch("wstat");
+  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
+  hipLaunchKernelGGL(kernel, dim3(ws_grid(a.njobs, ntiles)), dim3(WS_THREADS), lds, st, a);
+  return check_launch(what);
 }
 
-inline double ws_flops(int mode, const WsArgs& a) {
-  const double unit = 2.0 * WS_H * WS_H * (double)a.P * a.B;
-  return mode == WS_MLP2 ? 4 * unit : (mode == WS_SUM2 ? 2 * unit : unit);
+inline bool ws_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline int ws_check(const WsArgs& a, const char* what) {
+  if (a.P <= 0 || a.P % 4 != 0 || a.B <= 0) return fail(DPPM_E_INVALID, "%s: B=%d P=%d (P must be a positive multiple of 4)", what, a.B, a.P);
+  if (a.njobs < 1 || a.njobs > WS_MAX_JOBS) return fail(DPPM_E_INVALID, "%s: njobs=%d", what, a.njobs);
+  if (a.maskp && !ws_al16(a.maskp)) return fail(DPPM_E_INVALID, "%s: mask planes must be 16-byte aligned", what);
+  for (int i = 0; i < a.njobs; ++i) {
+    const WsJob& j = a.job[i];
+    if (!j.X || !j.W1 || !j.Y) return fail(DPPM_E_INVALID, "%s: null pointer in job %d", what, i);
+    if (!ws_al16(j.X) || !ws_al16(j.Y) || j.x_bs % 4 != 0 || j.y_bs % 4 != 0) return fail(DPPM_E_INVALID, "%s: planes must be 16-byte aligned", what);
+  }
+  return DPPM_OK;
 }
 
-inline int ws_launch(int mode, bool save_hid, const WsArgs& a, hipStream_t st) {
-  if (a.P % 4 != 0) return fail(DPPM_E_INVALID, "wstat: P=%d must be a multiple of 4", a.P);
+// Linear -> LeakyReLU -> Linear (* mask) for every job; save_mid keeps the hidden activations (training).
+inline int ws_mlp_forward(const WsArgs& a, bool save_mid, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "ws_mlp_forward"));
+  for (int i = 0; i < a.njobs; ++i) {
+    if (!a.job[i].W2) return fail(DPPM_E_INVALID, "ws_mlp_forward: job %d lacks its second matrix", i);
+    if (save_mid && (!a.job[i].Mid || !ws_al16(a.job[i].Mid) || a.job[i].mid_bs % 4)) return fail(DPPM_E_INVALID, "ws_mlp_forward: job %d: bad Mid", i);
+  }
+  static bool set0 = false, set1 = false;
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  const int rc = save_mid ? ws_launch_kernel(ws_mlp_kernel<false, false, true>, ws_mlp_lds(), a, st, set1, "ws_mlp_forward(save)")
+                          : ws_launch_kernel(ws_mlp_kernel<false, false, false>, ws_mlp_lds(), a, st, set0, "ws_mlp_forward");
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+// dpre = (W1^T dOut) * LeakyReLU'(hid) -> Mid ; Y (+)= W2^T dpre      (W1 = the MLP's second matrix, W2 = its first)
+inline int ws_mlp_backward(const WsArgs& a, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "ws_mlp_backward"));
+  for (int i = 0; i < a.njobs; ++i)
+    if (!a.job[i].W2 || !a.job[i].Hsaved || !a.job[i].Mid || !ws_al16(a.job[i].Hsaved) || !ws_al16(a.job[i].Mid) || a.job[i].hs_bs % 4 ||
+        a.job[i].mid_bs % 4)
+      return fail(DPPM_E_INVALID, "ws_mlp_backward: job %d needs W2 and 16-byte aligned Hsaved and Mid", i);
+  static bool set = false;
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  const int rc = ws_launch_kernel(ws_mlp_kernel<true, true, true>, ws_mlp_lds(), a, st, set, "ws_mlp_backward");
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+// Y (+)= epilogue(W1 X [+ W2 X2] + b1) for every job; trans applies the transposed matrices (data gradients).
+inline int ws_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "ws_lin"));
+  if (nsrc == 2)
+    for (int i = 0; i < a.njobs; ++i)
+      if (!a.job[i].X2 || !a.job[i].W2 || !ws_al16(a.job[i].X2) || a.job[i].x2_bs % 4) return fail(DPPM_E_INVALID, "ws_lin: job %d lacks its second source", i);
+  static bool set[4] = {false, false, false, false};
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   int rc;
-  if (mode == WS_MLP2) rc = save_hid ? ws_launch_one<WS_MLP2, true>(a, st) : ws_launch_one<WS_MLP2, false>(a, st);
-  else if (mode == WS_SUM2) rc = ws_launch_one<WS_SUM2, false>(a, st);
-  else rc = ws_launch_one<WS_COLS, false>(a, st);
-  if (prof) prof_after(st, mode == WS_MLP2 ? PROF_WS_MLP2 : (mode == WS_SUM2 ? PROF_WS_SUM2 : PROF_WS_COLS), ws_flops(mode, a));
+  if (nsrc == 1) rc = trans ? ws_launch_kernel(ws_lin_kernel<1, true>, ws_lin_lds(), a, st, set[0], "ws_lin<1,T>")
+                            : ws_launch_kernel(ws_lin_kernel<1, false>, ws_lin_lds(), a, st, set[1], "ws_lin<1,N>");
+  else rc = trans ? ws_launch_kernel(ws_lin_kernel<2, true>, ws_lin_lds(), a, st, set[2], "ws_lin<2,T>")
+                  : ws_launch_kernel(ws_lin_kernel<2, false>, ws_lin_lds(), a, st, set[3], "ws_lin<2,N>");
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs);
   return rc;
 }
 

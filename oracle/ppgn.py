@@ -33,7 +33,7 @@ def masked_instance_norm2d(x, mask, eps=1e-5):
 def powerful_layer(x, mask4, W, l):
     """model/ppgn.py:47-71.  x [B,N,N,H]; mask4 [B,N,N,1]."""
     pre = f"convs.{l}."
-    norm = mask4[:, 0].squeeze(-1).float().sum(-1).sqrt().view(mask4.size(0), 1, 1, 1)
+    norm = mask4[:, 0].squeeze(-1).sum(-1).sqrt().view(mask4.size(0), 1, 1, 1)
     m = mask4.unsqueeze(1).squeeze(-1)   # B,1,N,N
 
     def mlp(name):
@@ -48,15 +48,16 @@ def powerful_layer(x, mask4, W, l):
     return _lin(out, W[pre + "m4.0.weight"], W[pre + "m4.0.bias"])
 
 
-def powerful_forward(W, A, mask, noiselevel, num_layers, noise_mlp=False, return_intermediates=False):
+def powerful_forward(W, A, mask, noiselevel, num_layers, noise_mlp=False, return_intermediates=False, dtype=torch.float32):
     """W: dict name -> tensor (reference state_dict names); A, mask [B,N,N]; noiselevel float or [B].
-    Returns logits [B,N,N,1] (model/ppgn.py:257-337)."""
-    A = torch.as_tensor(A, dtype=torch.float32)
-    mask = torch.as_tensor(mask, dtype=torch.float32)
+    Returns logits [B,N,N,1] (model/ppgn.py:257-337).  dtype=torch.float64 (with float64 weights) evaluates the same graph in
+    double precision: the yardstick the tests use to separate rounding noise from errors."""
+    A = torch.as_tensor(A, dtype=dtype)
+    mask = torch.as_tensor(mask, dtype=dtype)
     B, N, _ = A.shape
     mask4 = mask[..., None]
     u = A[..., None]
-    sig = torch.as_tensor(np.asarray(noiselevel, dtype=np.float64).reshape(-1).astype(np.float32))
+    sig = torch.as_tensor(np.asarray(noiselevel, dtype=np.float64).reshape(-1).astype(np.float32)).to(dtype)
     if sig.numel() == 1:
         sig = sig.expand(B)
     if noise_mlp:   # ppgn.py:273-274: Linear(1,4) -> GELU -> Linear(4,1) on the scalar
