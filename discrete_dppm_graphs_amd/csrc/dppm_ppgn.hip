@@ -298,6 +298,24 @@ struct Ctx {
 
 struct Geo { int B, P; hipStream_t st; };
 
+// in_lin (model/ppgn.py:301): u0[b][c][p] = w[c][0] * A[b][p] + w[c][1] * sigmaI[b][p] + bias[c].  K = 2: pure streaming, one block
+// reads 1024 positions of the two input planes once and writes them for every channel.
+__global__ __launch_bounds__(256) void inlin_kernel(const float* __restrict__ cat, long cat_bs, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int H, int P, float* __restrict__ u0) {
+  const int b = blockIdx.y;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= P) return;
+  const float4 a = *reinterpret_cast<const float4*>(cat + (size_t)b * cat_bs + p);
+  const float4 s = *reinterpret_cast<const float4*>(cat + (size_t)b * cat_bs + P + p);
+  float* out = u0 + (size_t)b * H * P + p;
+  for (int c = 0; c < H; ++c) {
+    const float w0 = w[2 * c], w1 = w[2 * c + 1], bc = bias[c];
+    float4 v;
+    v.x = w0 * a.x + w1 * s.x + bc; v.y = w0 * a.y + w1 * s.y + bc; v.z = w0 * a.z + w1 * s.z + bc; v.w = w0 * a.w + w1 * s.w + bc;
+    *reinterpret_cast<float4*>(out + (size_t)c * P) = v;
+  }
+}
+
 // A/B switch for measurements: DPPM_DISABLE_WSTAT=1 routes the H = 128 linears through the generic GEMM family.
 inline bool use_wstat(int H) {
   static const bool off = getenv("DPPM_DISABLE_WSTAT") != nullptr;
@@ -524,7 +542,8 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   DPPM_TRY(check_launch("prep"));
 
   // in_lin: u0 = W_in (H x 2) * [A ; sigma I] + b     (model/ppgn.py:301)
-  DPPM_TRY(linear(c, H, LinArgs{pr->in_w, 2, false, cat, cat_bs, 2}, nullptr, pr->in_b, 0, nullptr, nullptr, 0, c.at(w.u0), hs, false));
+  hipLaunchKernelGGL(inlin_kernel, dim3(cdiv(P, 1024), B), dim3(256), 0, c.st, cat, cat_bs, pr->in_w, pr->in_b, H, P, c.at(w.u0));
+  DPPM_TRY(check_launch("in_lin"));
 
   for (int l = 0; l < L; ++l) {
     const dppm_ppgn_layer& q = pr->layers_host[l];
@@ -559,7 +578,22 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     DPPM_TRY(check_launch("inorm_fwd"));
   }
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)
-  DPPM_TRY(linear(c, H, LinArgs{pr->cat_w, w.CT, false, cat, cat_bs, w.CT}, nullptr, pr->cat_b, 0, nullptr, nullptr, 0, c.at(w.R), hs, false));
+  if (use_wstat(H)) {   // K = 2 + L*128: the layer outputs two at a time through the weight-stationary kernel, [A, sigma I] as a side input
+    for (int l0 = 0; l0 < L; l0 += 2) {
+      const int ns = L - l0 >= 2 ? 2 : 1;
+      WsArgs wa{};
+      wa.njobs = 1; wa.B = B; wa.P = P;
+      WsJob& j = wa.job[0];
+      j.X = cat + (size_t)(2 + l0 * H) * P; j.x_bs = cat_bs; j.W1 = pr->cat_w + 2 + (size_t)l0 * H; j.ldw1 = w.CT;
+      if (ns == 2) { j.X2 = cat + (size_t)(2 + (l0 + 1) * H) * P; j.x2_bs = cat_bs; j.W2 = pr->cat_w + 2 + (size_t)(l0 + 1) * H; j.ldw2 = w.CT; }
+      j.Y = c.at(w.R); j.y_bs = hs;
+      if (l0 == 0) { j.b1 = pr->cat_b; wa.side = cat; wa.side_bs = cat_bs; wa.wside = pr->cat_w; wa.ldws = w.CT; }
+      else j.accumulate = 1;
+      DPPM_TRY(ws_lin(wa, ns, false, c.st));
+    }
+  } else {
+    DPPM_TRY(linear(c, H, LinArgs{pr->cat_w, w.CT, false, cat, cat_bs, w.CT}, nullptr, pr->cat_b, 0, nullptr, nullptr, 0, c.at(w.R), hs, false));
+  }
   // out + LeakyReLU(after_conv(out)) ; final_lin   (model/ppgn.py:331-333)
   if (use_wstat(H)) {
     WsArgs wa{};

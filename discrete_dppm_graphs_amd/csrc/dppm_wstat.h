@@ -53,6 +53,9 @@ struct WsArgs {
   WsJob job[WS_MAX_JOBS];
   int njobs;
   const float* maskp;                 // [B][P] or null: multiplies the result
+  // lin, optional rank-2 side input (the [A, sigma I] planes of layer_cat_lin): result += wside[ch][0..1] . side[b][0..1][p]
+  const float* side; long side_bs;    // [B][2][P]
+  const float* wside; int ldws;       // [128][ldws], columns 0 and 1
   int act;                            // lin: LeakyReLU on the result
   int B, P;
 };
@@ -275,9 +278,23 @@ __global__ __launch_bounds__(WS_THREADS, 4) void ws_lin_kernel(const WsArgs a) {
       }
       ws_mma4<WS_XP>(acc, w[s], smem + cur * WS_XS + lane_off);
       if (more) ws_tile_store(pre, smem + (cur ^ 1) * WS_XS, tid);
-      if (last)
+      if (last) {
+        if (a.side) {   // uniform branch
+          const float s0 = a.wside[(size_t)ch * a.ldws], s1 = a.wside[(size_t)ch * a.ldws + 1];
+          const float* St = a.side + (size_t)b * a.side_bs + p0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((int)m0 + 16 * j < P - p0) {
+              const float4 x0 = *reinterpret_cast<const float4*>(St + m0 + 16 * j);
+              const float4 x1 = *reinterpret_cast<const float4*>(St + P + m0 + 16 * j);
+              acc[j][0] += s0 * x0.x + s1 * x1.x; acc[j][1] += s0 * x0.y + s1 * x1.y;
+              acc[j][2] += s0 * x0.z + s1 * x1.z; acc[j][3] += s0 * x0.w + s1 * x1.w;
+            }
+          }
+        }
         ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
                      J.accumulate != 0);
+      }
       __syncthreads();
       cur ^= 1;
     }
@@ -355,6 +372,7 @@ inline int ws_mlp_backward(const WsArgs& a, hipStream_t st) {
 // Y (+)= epilogue(W1 X [+ W2 X2] + b1) for every job; trans applies the transposed matrices (data gradients).
 inline int ws_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   DPPM_TRY(ws_check(a, "ws_lin"));
+  if (a.side && (!a.wside || !ws_al16(a.side) || a.side_bs % 4)) return fail(DPPM_E_INVALID, "ws_lin: bad side input");
   if (nsrc == 2)
     for (int i = 0; i < a.njobs; ++i)
       if (!a.job[i].X2 || !a.job[i].W2 || !ws_al16(a.job[i].X2) || a.job[i].x2_bs % 4) return fail(DPPM_E_INVALID, "ws_lin: job %d lacks its second source", i);
