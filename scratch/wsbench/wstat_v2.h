@@ -1,0 +1,391 @@
+// Weight-stationary kernels for the H = 128 PPGN linears (the bulk of the FLOPs: per layer 12 N^2 H^2 of
+// 12 N^2 H^2 + 2 H N^3).  In channel-first layout a Linear is Y (128 x P) = W (128 x 128) * X (128 x P) with P = N*ld
+// positions per graph: a tall-skinny problem whose only large dimension is P.  So the weights stay put and the
+// positions stream through:
+//   - persistent workgroups of 8 wave64, TWO per CU (independent barriers: one group's epilogue and staging overlap
+//     the other's MFMAs), walk 64-position tiles of all graphs;
+//   - wave w keeps the weights of output channels 16w .. 16w+15 in 32 VGPRs per matrix for the whole launch;
+//   - the X tile (128 channels x 64 positions, 32 KB) is staged through LDS (global -> registers while the previous
+//     tile computes -> LDS) and read by every wave as the MFMA A operand with conflict-free ds_read_b32;
+//   - v_mfma_f32_16x16x4_f32 computes D[position][channel] (exact f32), i.e. the transposed tile, so a lane ends up with
+//     four CONSECUTIVE positions of one channel: every store is a 16-byte store.  The k order inside the chain is
+//     k = 32 * (lane >> 4) + step so that a lane's 32 weights are one contiguous run of its row.
+// Kernels
+//   ws_mlp_kernel : Linear -> elementwise -> Linear with the intermediate in LDS.
+//                   forward  (model/ppgn.py:58-59):  out = (W2 LeakyReLU(W1 X + b1) + b2) * mask         [hid saved for training]
+//                   backward:                         dpre = (W1^T dOut) * LeakyReLU'(hid) [saved for the weight gradients],
+//                                                     dX (+)= W2^T dpre      (W1 = the MLP's second matrix, W2 = its first)
+//   ws_lin_kernel : Y (+)= epilogue(sum_s W_s X_s + b), one or two 128-channel sources (the skip-concat Linear m4 of
+//                   model/ppgn.py:66-69 without materialising the cat; after_conv; every transposed data-gradient form).
+// A launch carries up to 8 independent jobs (weights / sources / outputs); a workgroup serves one job for its lifetime
+// and jobs that read the same source sit on the same XCD so the second read of a tile is an L2 hit.
+
+#include <hip/hip_runtime.h>
+#include "dppm_gemm.h"
+
+namespace dppm { namespace v2 {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int WS_H = 128;          // channels handled by these kernels
+constexpr int WS_TP = 64;          // positions per tile
+constexpr int WS_THREADS = 512;
+constexpr int WS_XP = 64;          // LDS row pitch of a staged source tile (floats)
+constexpr int WS_HP = 68;          // LDS row pitch of the intermediate tile (16-byte writes from 16 rows at once stay conflict-free)
+constexpr int WS_XS = WS_H * WS_XP + 64;   // floats per staged tile incl. the 16-float skew per 32 rows
+constexpr int WS_HS = WS_H * WS_HP + 64;
+constexpr int WS_MAX_JOBS = 8;
+constexpr int WS_WG_PER_XCD = 64;  // 32 CUs x 2 resident workgroups
+
+struct WsJob {
+  const float* X;  long x_bs;      // source planes [B][128][P]
+  const float* X2; long x2_bs;     // ws_lin with two sources: the second one
+  const float* W1; const float* W2;   // mlp: first / second stage matrix;  lin: matrix of source 1 / source 2
+  int ldw1, ldw2;
+  const float* b1; const float* b2;   // mlp: stage biases; lin: b1 only (nullable)
+  const float* Hsaved; long hs_bs;    // mlp backward: the saved hidden activations
+  float* Mid; long mid_bs;            // mlp: where the intermediate is saved (SAVE_MID)
+  float* Y; long y_bs;
+  int accumulate;                     // Y += result
+};
+
+struct WsArgs {
+  WsJob job[WS_MAX_JOBS];
+  int njobs;
+  const float* maskp;                 // [B][P] or null: multiplies the result
+  // lin, optional rank-2 side input (the [A, sigma I] planes of layer_cat_lin): result += wside[ch][0..1] . side[b][0..1][p]
+  const float* side; long side_bs;    // [B][2][P]
+  const float* wside; int ldws;       // [128][ldws], columns 0 and 1
+  int act;                            // lin: LeakyReLU on the result
+  int B, P;
+};
+
+__device__ __forceinline__ int ws_hoff(int k) { return k * WS_HP + 16 * (k >> 5); }
+
+// a lane's 32 weights of output channel ch: w[s] = W[ch][32 g + s]   (TRANS: W^T, i.e. w[s] = W[32 g + s][ch])
+template <bool TRANS>
+__device__ __forceinline__ void ws_load_w(float (&w)[32], const float* __restrict__ W, int ldw, int ch, int g) {
+  if (TRANS) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) w[s] = W[(size_t)(32 * g + s) * ldw + ch];
+  } else {
+    const float* p = W + (size_t)ch * ldw + 32 * g;
+    if ((((uintptr_t)p) & 15) == 0) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float4 q = reinterpret_cast<const float4*>(p)[v];
+        w[4 * v + 0] = q.x; w[4 * v + 1] = q.y; w[4 * v + 2] = q.z; w[4 * v + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) w[s] = p[s];
+    }
+  }
+}
+
+// acc[j] (16 positions x 16 channels, j = 0..3) += T[:, 16 j ..]^T * Wslice^T ; T points at the lane's first element
+template <int PITCH>
+__device__ __forceinline__ void ws_mma4(floatx4 (&acc)[4], const float (&w)[32], const float* __restrict__ T) {
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[s * PITCH + 16 * j], w[s], acc[j], 0, 0, 0);
+  }
+}
+
+// global tile (128 rows x 64 positions) -> registers (4 float4 per thread) / registers -> LDS.
+// Xt: uniform pointer to (row 0, first position of the tile); o0 = (tid >> 4) * P + 4 * (tid & 15); ok: the lane's four
+// positions lie inside the plane.  Uniform base + 32-bit lane offset keeps the address math off the vector registers.
+__device__ __forceinline__ void ws_tile_load(float4 (&r)[4], const float* __restrict__ Xt, unsigned P, unsigned o0, bool ok) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const float* Xv = Xt + (size_t)(32 * v) * P;
+    r[v] = ok ? *reinterpret_cast<const float4*>(Xv + o0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void ws_tile_store(const float4 (&r)[4], float* __restrict__ T, int tid) {
+  float* q = T + (tid >> 4) * WS_XP + (tid & 15) * 4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(q + 32 * v * WS_XP + 16 * v) = r[v];   // row (tid >> 4) + 32 v, skew 16 v
+}
+
+struct WsWho { int jid, rank, per_job; };
+__device__ __forceinline__ WsWho ws_who(int njobs) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  WsWho w;
+  w.jid = __builtin_amdgcn_readfirstlane(slot % njobs);
+  w.rank = __builtin_amdgcn_readfirstlane((slot / njobs) * 8 + xcd);
+  w.per_job = __builtin_amdgcn_readfirstlane((int)(gridDim.x >> 3) / njobs * 8);
+  return w;
+}
+
+__device__ __forceinline__ float ws_leaky(float v) { return v > 0.f ? v : kSlope * v; }
+__device__ __forceinline__ float4 ws_f4(const floatx4& a) { return make_float4(a[0], a[1], a[2], a[3]); }
+
+// result tile -> global: optional LeakyReLU, mask, accumulate.  Yt / Mt: uniform pointers to the tile's first position;
+// r0 = ch * P + 4 g, m0 = 4 g: the lane's offsets; lim = positions left in the plane from the tile's start.
+__device__ __forceinline__ void ws_store_out(const floatx4 (&acc)[4], float* __restrict__ Yt, unsigned r0, const float* __restrict__ Mt,
+                                             unsigned m0, int lim, float bias, bool act, bool accumulate) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if ((int)m0 + 16 * j < lim) {
+      float4 v = ws_f4(acc[j]);
+      v.x += bias; v.y += bias; v.z += bias; v.w += bias;   // after the chain, as a GEMM epilogue would: one rounding at the bias' magnitude
+      if (act) { v.x = ws_leaky(v.x); v.y = ws_leaky(v.y); v.z = ws_leaky(v.z); v.w = ws_leaky(v.w); }
+      if (Mt) {
+        const float4 m = *reinterpret_cast<const float4*>(Mt + m0 + 16 * j);
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+      }
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(Yt + r0 + 16 * j);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(Yt + r0 + 16 * j) = v;
+    }
+  }
+}
+
+template <bool BWD, bool TRANS, bool SAVE_MID>
+__global__ __launch_bounds__(WS_THREADS, 4) void ws_mlp_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;
+  float* Hs = smem + WS_XS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * wave + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+
+  float w1[32], w2[32];
+  ws_load_w<TRANS>(w1, J.W1, J.ldw1, ch, g);
+  ws_load_w<TRANS>(w2, J.W2, J.ldw2, ch, g);
+  const float b1v = J.b1 ? J.b1[ch] : 0.f, b2v = J.b2 ? J.b2[ch] : 0.f;
+
+  const unsigned o0 = (unsigned)(tid >> 4) * P + 4 * (tid & 15);   // staging: row tid >> 4, 4 positions
+  const int oc = 4 * (tid & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;                    // results: row ch, positions 16 j + 4 g ..
+  const unsigned m0 = 4 * g;
+
+  float4 pre[4];
+  int t = who.rank;
+  if (t < ntiles) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    ws_tile_load(pre, J.X + (size_t)b * J.x_bs + p0, P, o0, p0 + oc < P);
+    ws_tile_store(pre, Xs, tid);
+  }
+  __syncthreads();
+
+  const float* xa = Xs + (32 * g) * WS_XP + 16 * g + ci;   // lane's A-operand base: row 32 g, position ci
+  const float* ha = Hs + (32 * g) * WS_HP + 16 * g + ci;
+  float* hw = Hs + ws_hoff(ch) + 4 * g;                    // lane's intermediate slot: row ch, positions 16 j + 4 g ..
+
+  for (; t < ntiles; t += who.per_job) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const int tn = t + who.per_job;
+    const int lim = P - p0;
+    float4 hs[4];
+    if (BWD) {
+      const float* Ht = J.Hsaved + (size_t)b * J.hs_bs + p0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hs[j] = ((int)m0 + 16 * j < lim) ? *reinterpret_cast<const float4*>(Ht + r0 + 16 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ws_mma4<WS_XP>(acc, w1, xa);
+    // ---- elementwise stage; intermediate to LDS (and to HBM when a later pass needs it)
+    float* Mt = SAVE_MID ? J.Mid + (size_t)b * J.mid_bs + p0 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v;
+      if (BWD) {
+        v.x = acc[j][0] * (hs[j].x > 0.f ? 1.f : kSlope); v.y = acc[j][1] * (hs[j].y > 0.f ? 1.f : kSlope);
+        v.z = acc[j][2] * (hs[j].z > 0.f ? 1.f : kSlope); v.w = acc[j][3] * (hs[j].w > 0.f ? 1.f : kSlope);
+      } else {
+        v.x = ws_leaky(acc[j][0] + b1v); v.y = ws_leaky(acc[j][1] + b1v); v.z = ws_leaky(acc[j][2] + b1v); v.w = ws_leaky(acc[j][3] + b1v);
+      }
+      *reinterpret_cast<float4*>(hw + 16 * j) = v;
+      if (SAVE_MID) {
+        if ((int)m0 + 16 * j < lim) *reinterpret_cast<float4*>(Mt + r0 + 16 * j) = v;
+      }
+    }
+    __syncthreads();
+    if (tn < ntiles) {   // next tile: in flight during stage 2
+      const int bn = __builtin_amdgcn_readfirstlane(tn / tpp), pn = __builtin_amdgcn_readfirstlane((tn % tpp) * WS_TP);
+      ws_tile_load(pre, J.X + (size_t)bn * J.x_bs + pn, P, o0, pn + oc < P);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ws_mma4<WS_HP>(acc, w2, ha);
+    if (tn < ntiles) ws_tile_store(pre, Xs, tid);          // every wave left stage 1 (the only reader of Xs) at the barrier above
+    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, lim, b2v, false,
+                 J.accumulate != 0);
+    __syncthreads();
+  }
+}
+
+template <int NSRC, bool TRANS>
+__global__ __launch_bounds__(WS_THREADS, 4) void ws_lin_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * wave + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+
+  float w[NSRC][32];
+  ws_load_w<TRANS>(w[0], J.W1, J.ldw1, ch, g);
+  if (NSRC == 2) ws_load_w<TRANS>(w[NSRC - 1], J.W2, J.ldw2, ch, g);
+  const float bv = J.b1 ? J.b1[ch] : 0.f;
+
+  const unsigned o0 = (unsigned)(tid >> 4) * P + 4 * (tid & 15);
+  const int oc = 4 * (tid & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+
+  float4 pre[4];
+  int t = who.rank;
+  if (t < ntiles) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    ws_tile_load(pre, J.X + (size_t)b * J.x_bs + p0, P, o0, p0 + oc < P);
+    ws_tile_store(pre, smem, tid);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  const int lane_off = (32 * g) * WS_XP + 16 * g + ci;
+  for (; t < ntiles; t += who.per_job) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const int tn = t + who.per_job;
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      // the tile that follows this one in the stream: the next source of the same positions, or source 0 of the next tile
+      const bool last = (s == NSRC - 1);
+      const bool more = last ? (tn < ntiles) : true;
+      if (more) {
+        if (last) {
+          const int bn = __builtin_amdgcn_readfirstlane(tn / tpp), pn = __builtin_amdgcn_readfirstlane((tn % tpp) * WS_TP);
+          ws_tile_load(pre, J.X + (size_t)bn * J.x_bs + pn, P, o0, pn + oc < P);
+        } else {
+          ws_tile_load(pre, J.X2 + (size_t)b * J.x2_bs + p0, P, o0, p0 + oc < P);
+        }
+      }
+      ws_mma4<WS_XP>(acc, w[s], smem + cur * WS_XS + lane_off);
+      if (more) ws_tile_store(pre, smem + (cur ^ 1) * WS_XS, tid);
+      if (last) {
+        if (a.side) {   // uniform branch
+          const float s0 = a.wside[(size_t)ch * a.ldws], s1 = a.wside[(size_t)ch * a.ldws + 1];
+          const float* St = a.side + (size_t)b * a.side_bs + p0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((int)m0 + 16 * j < P - p0) {
+              const float4 x0 = *reinterpret_cast<const float4*>(St + m0 + 16 * j);
+              const float4 x1 = *reinterpret_cast<const float4*>(St + P + m0 + 16 * j);
+              acc[j][0] += s0 * x0.x + s1 * x1.x; acc[j][1] += s0 * x0.y + s1 * x1.y;
+              acc[j][2] += s0 * x0.z + s1 * x1.z; acc[j][3] += s0 * x0.w + s1 * x1.w;
+            }
+          }
+        }
+        ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
+                     J.accumulate != 0);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+}
+
+inline size_t ws_mlp_lds() { return (size_t)(WS_XS + WS_HS) * sizeof(float); }
+inline size_t ws_lin_lds() { return (size_t)(2 * WS_XS) * sizeof(float); }
+
+inline int ws_grid(int njobs, long ntiles) {
+  long slots = WS_WG_PER_XCD / njobs;                 // workgroups per job and XCD
+  const long need = (ntiles + 7) / 8;
+  if (slots > need) slots = need;
+  if (slots < 1) slots = 1;
+  return (int)(8 * njobs * slots);
+}
+
+template <typename K>
+inline int ws_launch_kernel(K kernel, size_t lds, const WsArgs& a, hipStream_t st, bool& attr_set, const char* what) {
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "%s: cannot raise the dynamic LDS limit to %zu bytes", what, lds);
+    attr_set = true;
+  }
+  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
+  hipLaunchKernelGGL(kernel, dim3(ws_grid(a.njobs, ntiles)), dim3(WS_THREADS), lds, st, a);
+  return check_launch(what);
+}
+
+inline bool ws_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline int ws_check(const WsArgs& a, const char* what) {
+  if (a.P <= 0 || a.P % 4 != 0 || a.B <= 0) return fail(DPPM_E_INVALID, "%s: B=%d P=%d (P must be a positive multiple of 4)", what, a.B, a.P);
+  if (a.njobs < 1 || a.njobs > WS_MAX_JOBS) return fail(DPPM_E_INVALID, "%s: njobs=%d", what, a.njobs);
+  if (a.maskp && !ws_al16(a.maskp)) return fail(DPPM_E_INVALID, "%s: mask planes must be 16-byte aligned", what);
+  for (int i = 0; i < a.njobs; ++i) {
+    const WsJob& j = a.job[i];
+    if (!j.X || !j.W1 || !j.Y) return fail(DPPM_E_INVALID, "%s: null pointer in job %d", what, i);
+    if (!ws_al16(j.X) || !ws_al16(j.Y) || j.x_bs % 4 != 0 || j.y_bs % 4 != 0) return fail(DPPM_E_INVALID, "%s: planes must be 16-byte aligned", what);
+  }
+  return DPPM_OK;
+}
+
+// Linear -> LeakyReLU -> Linear (* mask) for every job; save_mid keeps the hidden activations (training).
+inline int ws_mlp_forward(const WsArgs& a, bool save_mid, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "ws_mlp_forward"));
+  for (int i = 0; i < a.njobs; ++i) {
+    if (!a.job[i].W2) return fail(DPPM_E_INVALID, "ws_mlp_forward: job %d lacks its second matrix", i);
+    if (save_mid && (!a.job[i].Mid || !ws_al16(a.job[i].Mid) || a.job[i].mid_bs % 4)) return fail(DPPM_E_INVALID, "ws_mlp_forward: job %d: bad Mid", i);
+  }
+  static bool set0 = false, set1 = false;
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  const int rc = save_mid ? ws_launch_kernel(ws_mlp_kernel<false, false, true>, ws_mlp_lds(), a, st, set1, "ws_mlp_forward(save)")
+                          : ws_launch_kernel(ws_mlp_kernel<false, false, false>, ws_mlp_lds(), a, st, set0, "ws_mlp_forward");
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+// dpre = (W1^T dOut) * LeakyReLU'(hid) -> Mid ; Y (+)= W2^T dpre      (W1 = the MLP's second matrix, W2 = its first)
+inline int ws_mlp_backward(const WsArgs& a, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "ws_mlp_backward"));
+  for (int i = 0; i < a.njobs; ++i)
+    if (!a.job[i].W2 || !a.job[i].Hsaved || !a.job[i].Mid || !ws_al16(a.job[i].Hsaved) || !ws_al16(a.job[i].Mid) || a.job[i].hs_bs % 4 ||
+        a.job[i].mid_bs % 4)
+      return fail(DPPM_E_INVALID, "ws_mlp_backward: job %d needs W2 and 16-byte aligned Hsaved and Mid", i);
+  static bool set = false;
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  const int rc = ws_launch_kernel(ws_mlp_kernel<true, true, true>, ws_mlp_lds(), a, st, set, "ws_mlp_backward");
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+// Y (+)= epilogue(W1 X [+ W2 X2] + b1) for every job; trans applies the transposed matrices (data gradients).
+inline int ws_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "ws_lin"));
+  if (a.side && (!a.wside || !ws_al16(a.side) || a.side_bs % 4)) return fail(DPPM_E_INVALID, "ws_lin: bad side input");
+  if (nsrc == 2)
+    for (int i = 0; i < a.njobs; ++i)
+      if (!a.job[i].X2 || !a.job[i].W2 || !ws_al16(a.job[i].X2) || a.job[i].x2_bs % 4) return fail(DPPM_E_INVALID, "ws_lin: job %d lacks its second source", i);
+  static bool set[4] = {false, false, false, false};
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  int rc;
+  if (nsrc == 1) rc = trans ? ws_launch_kernel(ws_lin_kernel<1, true>, ws_lin_lds(), a, st, set[0], "ws_lin<1,T>")
+                            : ws_launch_kernel(ws_lin_kernel<1, false>, ws_lin_lds(), a, st, set[1], "ws_lin<1,N>");
+  else rc = trans ? ws_launch_kernel(ws_lin_kernel<2, true>, ws_lin_lds(), a, st, set[2], "ws_lin<2,T>")
+                  : ws_launch_kernel(ws_lin_kernel<2, false>, ws_lin_lds(), a, st, set[3], "ws_lin<2,N>");
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+} }  // namespace dppm::v2

@@ -150,6 +150,18 @@ def test_backward_kinkfree_h128(ops, shift1, shift2, shift_ac):
         assert err_gpu <= 4 * err_f32 + 2e-4 * scale, f"{n}: gpu {err_gpu:.3e} vs torch-f32 {err_f32:.3e} (scale {scale:.3e})"
 
 
+def test_forward_n512_h128(ops):
+    """BASELINE configs[4] geometry (N=512, H=128), one graph and one layer: logits against the oracle."""
+    from oracle import ppgn as op
+    rng = np.random.default_rng(512)
+    A, mask = rand_case(rng, 1, 512)
+    W = op.init_weights(1, 128, seed=3)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, 0.3, 1).squeeze(-1).numpy()
+    logits, _ = run_gpu(ops, W, A, mask, 0.3, 1, 128)
+    close(logits, ref)
+
+
 def test_inference_equals_training_forward(ops):
     from oracle import ppgn as op
     rng = np.random.default_rng(3)
@@ -157,7 +169,8 @@ def test_inference_equals_training_forward(ops):
     W = op.init_weights(2, 32, seed=1)
     a, _ = run_gpu(ops, W, A, mask, 0.2, 2, 32)
     b, _ = run_gpu(ops, W, A, mask, 0.2, 2, 32, dlogits=np.zeros_like(A))
-    assert np.array_equal(a, b)
+    # inference fuses the instance norm into its neighbours (statistics in double, one-pass): same values up to rounding
+    close(a, b, tol=1e-5)
 
 
 @pytest.mark.parametrize("n", [5, 32, 33, 40, 64, 100, 200])
