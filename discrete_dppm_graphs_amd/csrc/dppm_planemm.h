@@ -90,6 +90,28 @@ __device__ __forceinline__ void plane_store(const float4* r, float* __restrict__
   }
 }
 
+// One finished 16 x 16 tile, held TRANSPOSED (the MFMA was issued with its operands swapped: D = B_frag^T-by-A_frag, so
+// the lane's four registers are four CONSECUTIVE COLUMNS of one row): row = row0 + (lane & 15), cols = col0 + 4 (lane >> 4) ..
+// One 16-byte store per lane and tile instead of four 4-byte ones (the epilogue of the 4-byte form was store-issue bound:
+// a third of the kernel at N = 200).  Columns in [n, ld) are written as zeros; ld % 4 == 0 keeps the vector inside the row.
+__device__ __forceinline__ void plane_store_tile(const floatx4& acc, float* __restrict__ C, const float* __restrict__ mask, float scale,
+                                                 int row0, int col0, int n, int ld, int lane) {
+  const int row = row0 + (lane & 15), col = col0 + 4 * (lane >> 4);
+  if (row < n && col < ld) {
+    float4 v = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+    if (mask) {
+      const float4 m = *reinterpret_cast<const float4*>(mask + (size_t)row * ld + col);
+      v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    }
+    const int lim = n - col;
+    if (lim < 1) v.x = 0.f;
+    if (lim < 2) v.y = 0.f;
+    if (lim < 3) v.z = 0.f;
+    if (lim < 4) v.w = 0.f;
+    *reinterpret_cast<float4*>(C + (size_t)row * ld + col) = v;
+  }
+}
+
 // blockDim.x = 64 * ceil(n/16) (one wave per 16-row strip), grid.x = number of planes
 // waves per SIMD to aim for: as many whole workgroups of NT waves as the CU's 32 wave slots hold (register budget permitting)
 #ifndef DPPM_PLANE_FORCE_OCC
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(NT * 64, plane_waves_per_simd(NT)) void plane_mm_ke
       const float af = at[ks * 4 * Cfg::LDT];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bt[ks * 4 * Cfg::LDT + j * 16], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bt[ks * 4 * Cfg::LDT + j * 16], af, acc[j], 0, 0, 0);   // operands swapped: transposed tile
     }
     if (more) {
       plane_store<NT, A_KMAJOR, NVPT>(ra, lds + (stage ^ 1) * 2 * Cfg::PANEL, n, k0 + BK, tid, nthreads);
@@ -145,26 +167,11 @@ __global__ __launch_bounds__(NT * 64, plane_waves_per_simd(NT)) void plane_mm_ke
     stage ^= 1;
   }
 
-  // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
   const float scale = p.scale ? p.scale[g / p.div] : 1.f;
   const float* mask = p.mask ? p.mask + (size_t)(g / p.div) * plane : nullptr;
   float* C = p.C + g * plane;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = j * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wave * 16 + 4 * (lane >> 4) + r;
-      if (row < n && col < ld) {
-        float v = 0.f;
-        if (col < n) {
-          v = acc[j][r] * scale;
-          if (mask) v *= mask[(size_t)row * ld + col];
-        }
-        C[(size_t)row * ld + col] = v;
-      }
-    }
-  }
+  for (int j = 0; j < NT; ++j) plane_store_tile(acc[j], C, mask, scale, wave * 16, j * 16, n, ld, lane);
 }
 
 template <int NT>
@@ -283,7 +290,7 @@ __device__ __forceinline__ void p16_body(const PlaneArgs& p, float* lds, int g, 
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
-          for (int j = 0; j < NC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);   // swapped: transposed tile
       };
 #pragma unroll
       for (int ks = 0; ks < PBK / 4; ++ks) kstep(ks);
@@ -301,21 +308,7 @@ __device__ __forceinline__ void p16_body(const PlaneArgs& p, float* lds, int g, 
 #pragma unroll
   for (int i = 0; i < NR; ++i)
 #pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      const int col = (c0 + j) * 16 + (lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (r0 + i) * 16 + 4 * (lane >> 4) + r;
-        if (row < n && col < ld) {
-          float v = 0.f;
-          if (col < n) {
-            v = acc[i][j][r] * scale;
-            if (mask) v *= mask[(size_t)row * ld + col];
-          }
-          C[(size_t)row * ld + col] = v;
-        }
-      }
-    }
+    for (int j = 0; j < NC; ++j) plane_store_tile(acc[i][j], C, mask, scale, (r0 + i) * 16, (c0 + j) * 16, n, ld, lane);
 }
 
 template <int NT, int PBK, bool A_KMAJOR, bool B_KMAJOR>

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from discrete_dppm_graphs_amd import ops
 n=int(sys.argv[1]) if len(sys.argv)>1 else 200
 ld=(n+3)//4*4; batch=4096
