@@ -11,6 +11,7 @@
 // so the reference's permutes and cats never cost a byte.  All GEMMs run on v_mfma_f32_32x32x2_f32 (dppm_gemm.h).
 #include "dppm_gemm.h"
 #include "dppm_wstat.h"
+#include "dppm_wgrad.h"
 #include "dppm_planemm.h"
 #include <cstdlib>
 
@@ -73,6 +74,7 @@ Layout make_layout(int B, int N, int H, int L, int training) {
     w.du0 = bump(off, w.S);
     const int nz = B * wgrad_nsplit(B, w.P);
     w.slab_floats = (size_t)nz * H * (size_t)(w.CT > 2 * H ? w.CT : 2 * H);
+    if (H == WS_H && w.slab_floats < ws_wgrad_scratch_floats()) w.slab_floats = ws_wgrad_scratch_floats();
     w.slabs = bump(off, w.slab_floats);
     w.rsum = bump(off, (size_t)nz * H + (size_t)B * H + B);
   }
@@ -413,6 +415,8 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
   return DPPM_OK;
 }
 int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
+  if (use_wstat(M) && Nw == WS_H && c.w.slab_floats >= ws_wgrad_scratch_floats())   // register-resident split-K form (dppm_wgrad.h)
+    return ws_wgrad(dY, dy_bs, X, x_bs, c.w.B, c.w.P, dW, ldo, db, c.at(c.w.slabs), c.st);
   return wgrad_raw(Geo{c.w.B, c.w.P, c.st}, M, dY, dy_bs, Nw, X, x_bs, dW, ldo, db, c.at(c.w.slabs), c.w.slab_floats, c.at(c.w.rsum));
 }
 
@@ -659,7 +663,13 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, true, dz, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dh, hs, true));
   }
   // layer_cat_lin
-  DPPM_TRY(wgrad(c, H, dh, hs, w.CT, cat, cat_bs, gr->cat_w, w.CT, gr->cat_b));
+  if (ws) {   // one 128 x 128 block per layer output, then the two input columns
+    for (int j = 0; j < L; ++j)
+      DPPM_TRY(wgrad(c, H, dh, hs, H, cat + (size_t)(2 + j * H) * P, cat_bs, gr->cat_w + 2 + (size_t)j * H, w.CT, j == 0 ? gr->cat_b : nullptr));
+    DPPM_TRY(wgrad(c, H, dh, hs, 2, cat, cat_bs, gr->cat_w, w.CT, nullptr));
+  } else {
+    DPPM_TRY(wgrad(c, H, dh, hs, w.CT, cat, cat_bs, gr->cat_w, w.CT, gr->cat_b));
+  }
   if (ws) {   // d u_j = W_cat[:, 2 + jH ..]^T dh, one job per layer output (rows 0, 1 of dcat - the inputs - have no consumer)
     for (int j0 = 0; j0 < L; j0 += WS_MAX_JOBS) {
       WsArgs wa{};

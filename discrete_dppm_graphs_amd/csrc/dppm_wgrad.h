@@ -1,0 +1,172 @@
+// Weight gradients of the H = 128 linears: dW (128 x 128) = sum_{b,p} dY[b][:, p] X[b][:, p]^T, db = sum_{b,p} dY[b][:, p].
+// The reduction runs over all B * P positions (1.3 M at N = 200, B = 32): a split-K problem with a tiny output.
+//   - 512 persistent workgroups (two per CU) stride through 64-position tiles and keep their 128 x 128 partial product
+//     in registers (8 waves x 32 accumulator registers) for the whole launch: one slab per workgroup, not per tile;
+//   - both operands are staged in their NATURAL layout ([channel][position], a straight 16-byte copy): with a row pitch of
+//     68 floats the MFMA fragment reads (16 channels x 4 consecutive positions per wave) touch 64 distinct banks, so the
+//     transposition an operand with K contiguous usually needs never happens;
+//   - v_mfma_f32_16x16x4_f32 with k = position: D[m][n] += dY[m][p] * X[n][p];
+//   - slabs are folded by a two-stage reduction in a fixed order (bitwise reproducible run to run).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dppm_gemm.h"
+#include "dppm_wstat.h"
+
+namespace dppm {
+
+constexpr int WG_TP = 64;              // positions per tile
+constexpr int WG_PITCH = 68;           // LDS row pitch (floats)
+constexpr int WG_THREADS = 512;
+constexpr int WG_GRID = 512;           // slabs per launch
+constexpr int WG_SLAB = WS_H * WS_H + WS_H;   // floats per slab: dW then db
+constexpr int WG_ZC = 32;              // first-stage groups of the slab reduction
+
+struct WgArgs {
+  const float* dY; long dy_bs;         // [B][128][P]
+  const float* X;  long x_bs;          // [B][128][P]
+  float* slabs;                        // [gridDim.x][WG_SLAB]
+  int B, P;
+};
+
+__device__ __forceinline__ void wg_tile_load(float4 (&r)[4], const float* __restrict__ Xt, unsigned P, unsigned o0, bool ok) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) r[v] = ok ? *reinterpret_cast<const float4*>(Xt + (size_t)(32 * v) * P + o0) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void wg_tile_store(const float4 (&r)[4], float* __restrict__ T, int tid) {
+  float* q = T + (tid >> 4) * WG_PITCH + (tid & 15) * 4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(q + 32 * v * WG_PITCH) = r[v];
+}
+
+template <bool WITH_DB>
+__global__ __launch_bounds__(WG_THREADS, 4) void ws_wgrad_kernel(const WgArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ys[WS_H * WG_PITCH];
+  __shared__ __attribute__((aligned(16))) float Xs[WS_H * WG_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, ci = lane & 15;
+  const int wm = wave >> 2, wn = wave & 3;           // this wave: rows 64 wm .. +63 of dW, columns 32 wn .. +31
+  const int P = a.P, tpp = (P + WG_TP - 1) / WG_TP, ntiles = a.B * tpp;
+  const unsigned o0 = (unsigned)(tid >> 4) * P + 4 * (tid & 15);
+  const int oc = 4 * (tid & 15);
+
+  floatx4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float dbv[4] = {0.f, 0.f, 0.f, 0.f};               // row sums of dY for rows (tid >> 4) + 32 v
+
+  float4 py[4], px[4];
+  int t = blockIdx.x;
+  if (t < ntiles) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WG_TP);
+    wg_tile_load(py, a.dY + (size_t)b * a.dy_bs + p0, P, o0, p0 + oc < P);
+    wg_tile_load(px, a.X + (size_t)b * a.x_bs + p0, P, o0, p0 + oc < P);
+    wg_tile_store(py, Ys, tid);
+    wg_tile_store(px, Xs, tid);
+    if (WITH_DB) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dbv[v] += (py[v].x + py[v].y) + (py[v].z + py[v].w);
+    }
+  }
+  __syncthreads();
+
+  const float* ya = Ys + (64 * wm + ci) * WG_PITCH + g;    // A fragment: channel 64 wm + 16 i + ci, position 4 k + g
+  const float* xb = Xs + (32 * wn + ci) * WG_PITCH + g;    // B fragment: channel 32 wn + 16 j + ci, position 4 k + g
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) {
+      const int b = __builtin_amdgcn_readfirstlane(tn / tpp), p0 = __builtin_amdgcn_readfirstlane((tn % tpp) * WG_TP);
+      wg_tile_load(py, a.dY + (size_t)b * a.dy_bs + p0, P, o0, p0 + oc < P);
+      wg_tile_load(px, a.X + (size_t)b * a.x_bs + p0, P, o0, p0 + oc < P);
+    }
+#pragma unroll
+    for (int k = 0; k < WG_TP / 4; ++k) {
+      float af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = ya[16 * i * WG_PITCH + 4 * k];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = xb[16 * j * WG_PITCH + 4 * k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (tn < ntiles) {
+      wg_tile_store(py, Ys, tid);
+      wg_tile_store(px, Xs, tid);
+      if (WITH_DB) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dbv[v] += (py[v].x + py[v].y) + (py[v].z + py[v].w);
+      }
+    }
+    __syncthreads();
+  }
+
+  // this workgroup's slab: D[m = 4 g + r][n = ci] of tile (i, j)
+  float* slab = a.slabs + (size_t)blockIdx.x * WG_SLAB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(64 * wm + 16 * i + 4 * g + r) * WS_H + 32 * wn + 16 * j + ci] = acc[i][j][r];
+  if (WITH_DB) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float s = dbv[v];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      if ((tid & 15) == 0) slab[WS_H * WS_H + (tid >> 4) + 32 * v] = s;
+    }
+  }
+}
+
+// stage 1: part[zc][e] = sum of slabs zc * per .. (zc + 1) * per - 1 ; stage 2: out = sum_zc part[zc][e]   (fixed orders)
+__global__ __launch_bounds__(256) void wg_reduce1_kernel(const float* __restrict__ slabs, int nz, int per, int ne, int stride,
+                                                         float* __restrict__ part) {
+  const int e = blockIdx.x * 256 + threadIdx.x, zc = blockIdx.y;
+  if (e >= ne) return;
+  const int z0 = zc * per, z1 = z0 + per < nz ? z0 + per : nz;
+  float s = 0.f;
+  for (int z = z0; z < z1; ++z) s += slabs[(size_t)z * stride + e];
+  part[(size_t)zc * ne + e] = s;
+}
+__global__ __launch_bounds__(256) void wg_reduce2_kernel(const float* __restrict__ part, int nzc, int ne, float* __restrict__ dW, int ldo,
+                                                         float* __restrict__ db) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= ne) return;
+  float s = 0.f;
+  for (int z = 0; z < nzc; ++z) s += part[(size_t)z * ne + e];
+  if (e < WS_H * WS_H) dW[(size_t)(e / WS_H) * ldo + (e % WS_H)] = s;
+  else if (db) db[e - WS_H * WS_H] = s;
+}
+
+inline size_t ws_wgrad_scratch_floats() { return (size_t)WG_GRID * WG_SLAB + (size_t)WG_ZC * WG_SLAB; }
+
+// dW (128 x 128, row pitch ldo) and optionally db from dY and X, both [B][128][P].  scratch: ws_wgrad_scratch_floats().
+inline int ws_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int B, int P, float* dW, int ldo, float* db, float* scratch,
+                    hipStream_t st) {
+  if (!dY || !X || !dW || !scratch || B <= 0 || P <= 0 || P % 4 != 0) return fail(DPPM_E_INVALID, "ws_wgrad: bad arguments");
+  if (!ws_al16(dY) || !ws_al16(X) || dy_bs % 4 != 0 || x_bs % 4 != 0) return fail(DPPM_E_INVALID, "ws_wgrad: planes must be 16-byte aligned");
+  if ((long)WS_H * P >= (1L << 31)) return fail(DPPM_E_INVALID, "ws_wgrad: P=%d too large", P);
+  const long ntiles = (long)B * ((P + WG_TP - 1) / WG_TP);
+  const int grid = (int)(ntiles < WG_GRID ? ntiles : WG_GRID);
+  WgArgs a{dY, dy_bs, X, x_bs, scratch, B, P};
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  if (db) hipLaunchKernelGGL(ws_wgrad_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(ws_wgrad_kernel<false>, dim3(grid), dim3(WG_THREADS), 0, st, a);
+  if (prof) prof_after(st, PROF_WGRAD, 2.0 * WS_H * WS_H * (double)P * B);
+  DPPM_TRY(check_launch("ws_wgrad"));
+  const int ne = db ? WG_SLAB : WS_H * WS_H;
+  const int per = (grid + WG_ZC - 1) / WG_ZC, nzc = (grid + per - 1) / per;
+  float* part = scratch + (size_t)WG_GRID * WG_SLAB;
+  hipLaunchKernelGGL(wg_reduce1_kernel, dim3((ne + 255) / 256, nzc), dim3(256), 0, st, scratch, grid, per, ne, WG_SLAB, part);
+  DPPM_TRY(check_launch("wg_reduce1"));
+  hipLaunchKernelGGL(wg_reduce2_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, part, nzc, ne, dW, ldo, db);
+  return check_launch("wg_reduce2");
+}
+
+}  // namespace dppm

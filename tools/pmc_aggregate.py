@@ -11,7 +11,7 @@ import json
 import sys
 from collections import defaultdict
 
-CLASS_OF = (("wstat_kernel<0", "wstat_mlp2"), ("wstat_kernel<1", "wstat_sum2"), ("wstat_kernel<2", "wstat_cols"),
+CLASS_OF = (("ws_mlp_kernel", "wstat_mlp2"), ("ws_lin_kernel<2", "wstat_sum2"), ("ws_lin_kernel<1", "wstat_cols"),
             ("plane_mm", "plane_matmul"), ("inorm_fwd", "inorm"), ("gemm_f32_kernel", "linear_gemm"))
 
 
