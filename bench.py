@@ -169,7 +169,7 @@ def main():
         # dominant kernel: the fused MLP pair when H = 128 (weight-stationary path), else the generic linear GEMM
         dom_key = "wstat_mlp2" if prof["wstat_mlp2"]["launches"] > 0 else "linear_gemm"
         dom = prof[dom_key]
-        dom_name = {"wstat_mlp2": "wstat_kernel<WS_MLP2,false> (both per-position MLPs of a PPGN layer, v_mfma_f32_32x32x2_f32; "
+        dom_name = {"wstat_mlp2": "ws_mlp_kernel<false,false,false> (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32; "
                                   "8*H^2*P*B FLOP per launch)",
                     "linear_gemm": "gemm_f32_kernel<...,TAG=0> (per-position linear layers, v_mfma_f32_32x32x2_f32)"}[dom_key]
         F = fwd_flops_per_graph(N, H, L)
@@ -192,7 +192,7 @@ def main():
                          "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "flops_per_launch": dom["work"] / max(dom["launches"], 1),
                          "share_of_step_time": dom["ms"] * 1e-3 / dt, "records_truncated": truncated},
-            "roofline_linear_all": {"kernel": "every per-position linear layer (wstat MLP2 / SUM2 / COLS + generic GEMM for in_lin, layer_cat_lin)",
+            "roofline_linear_all": {"kernel": "every per-position linear layer (ws_mlp_kernel, ws_lin_kernel<2>, ws_lin_kernel<1>; generic GEMM when H != 128)",
                                     "bound": "mfma", "achieved": tf(lin), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf(lin) / F32_MFMA_PEAK_TFLOPS, "share_of_step_time": lin["ms"] * 1e-3 / dt,
                                     "by_kernel": {k: {"tflops": tf(prof[k]), "launches": prof[k]["launches"],
