@@ -91,6 +91,30 @@ class FlatState:
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr, self.betas[0],
                       self.betas[1], self.eps, self.weight_decay, self.step_count)
 
+    def state_dict(self):
+        """Optimizer state as saved in the checkpoint's 'optimizer_state_dict' (flat moments + hyper-parameters)."""
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr,
+                'betas': list(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay, 'names': list(self.names),
+                'offsets': list(self.offsets)}
+
+    def load_state_dict(self, sd):
+        """Restore what state_dict() saved.  The moments must belong to the same parameter layout (names / offsets are
+        checked when present); a reference checkpoint's torch.optim.Adam state is not accepted here - its per-parameter
+        tensors are keyed by index over ALL parameters, not by name."""
+        if 'exp_avg' not in sd or 'exp_avg_sq' not in sd:
+            raise ValueError("FlatState.load_state_dict: not a flat optimizer state (a torch.optim.Adam state_dict cannot be resumed)")
+        if 'names' in sd and list(sd['names']) != list(self.names):
+            raise ValueError("FlatState.load_state_dict: parameter names differ from this model's")
+        if sd['exp_avg'].numel() != self.exp_avg.numel():
+            raise ValueError("FlatState.load_state_dict: moment size %d != %d" % (sd['exp_avg'].numel(), self.exp_avg.numel()))
+        self.exp_avg.copy_(sd['exp_avg'].to(self.exp_avg.device))
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'].to(self.exp_avg_sq.device))
+        self.step_count = int(sd['step'])
+        self.lr = float(sd.get('lr', self.lr))
+        self.betas = tuple(sd.get('betas', self.betas))
+        self.eps = float(sd.get('eps', self.eps))
+        self.weight_decay = float(sd.get('weight_decay', self.weight_decay))
+
     def publish_grads(self):
         """Expose the flat bucket as .grad on the parameters (for callers that want to inspect or clip)."""
         for name, p in zip(self.names, self.model._used_params()):

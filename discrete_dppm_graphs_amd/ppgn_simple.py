@@ -54,13 +54,24 @@ def _save(config, model, state, scheduler_state, sigma_list, epoch, train_loss, 
     to_save = {'model': model.state_dict(), 'sigma_list': [float(s) for s in sigma_list], 'config': edict2dict(config),
                'epoch': epoch, 'train_loss': float(train_loss), 'test_loss': float(test_loss),
                'train_loss_item': float('nan'), 'test_loss_item': float('nan'),
-               'optimizer_state_dict': {'step': state.step_count, 'exp_avg': state.exp_avg, 'exp_avg_sq': state.exp_avg_sq,
-                                        'lr': state.lr, 'betas': list(state.betas), 'eps': state.eps,
-                                        'weight_decay': state.weight_decay},
-               'scheduler_state_dict': scheduler_state}
+               'optimizer_state_dict': state.state_dict(), 'scheduler_state_dict': scheduler_state}
     d = os.path.join(config.model_save_dir, sub) if sub else config.model_save_dir
     os.makedirs(d, exist_ok=True)
     torch.save(to_save, os.path.join(d, f"{config.dataset.name}.pth"))
+
+
+def _resume(resume, model, state, config, lr0, gamma):
+    """Load a checkpoint written by _save into (model, state); returns (lr0, gamma, first_epoch)."""
+    ckp = torch.load(resume, map_location=config.dev, weights_only=True) if isinstance(resume, (str, os.PathLike)) else resume
+    model.load_state_dict(ckp['model'], strict=False)
+    state.load_state_dict(ckp['optimizer_state_dict'])
+    sched = ckp.get('scheduler_state_dict') or {}
+    lr0 = float(sched.get('base_lr', lr0))
+    gamma = float(sched.get('gamma', gamma))
+    first_epoch = int(ckp['epoch']) + 1
+    state.lr = lr0 * gamma ** first_epoch
+    logging.info(f"resumed from epoch {ckp['epoch']} (step {state.step_count}, lr {state.lr:.3e})")
+    return lr0, gamma, first_epoch
 
 
 def _epoch_loop(model, state, dl, config, step_fn, train, epoch, counters):
@@ -87,9 +98,12 @@ def _epoch_loop(model, state, dl, config, step_fn, train, epoch, counters):
 
 
 def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20, config=None, save_interval=50,
-        sample_interval=1, sigma_length=None, sample_from_sigma_delta=0.0, test_dl=None, samplers=_SAMPLERS):
+        sample_interval=1, sigma_length=None, sample_from_sigma_delta=0.0, test_dl=None, samplers=_SAMPLERS, resume=None):
     """reference ppgn_simple.py:37-237.  `optimizer` may be a torch.optim.Adam (its hyper-parameters are adopted; the
-    step itself runs in the fused HIP Adam over the flat parameter bucket) or an engine.FlatState."""
+    step itself runs in the fused HIP Adam over the flat parameter bucket) or an engine.FlatState.
+    resume: a checkpoint dict written by this module (or its path): weights, Adam moments, step count, the learning-rate
+    schedule and the epoch counter continue where they stopped (the reference saves these fields but never reads them
+    back, ppgn_simple.py:138-171)."""
     dist, rank, world = _dist()
     if isinstance(optimizer, engine.FlatState):
         state = optimizer
@@ -97,6 +111,9 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
         g = optimizer.param_groups[0]
         state = engine.FlatState(model, lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'], weight_decay=g['weight_decay'])
     lr0, gamma = state.lr, config.train.lr_dacey
+    first_epoch = 0
+    if resume is not None:
+        lr0, gamma, first_epoch = _resume(resume, model, state, config, lr0, gamma)
     best_score, best_score_loss = np.inf, np.inf
     lastmmd = {n: {"degree": 0, "cluster": 0, "orbit": 0.0} for n in config.num_levels}
     host_rng = np.random      # the reference draws sigmas from numpy's global generator (ppgn_simple.py:67)
@@ -113,7 +130,7 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
         return loss
 
     sigma_list = [0.0]
-    for epoch in range(max_epoch):
+    for epoch in range(first_epoch, max_epoch):
         t_start = time.time()
         model.train()
         mean_train_loss = _epoch_loop(model, state, train_dl, config, step_fn, True, epoch, counters)
@@ -161,7 +178,8 @@ def train_main(config, args):
     state = engine.FlatState(model, lr=config.train.lr_init, betas=(0.9, 0.999), eps=1e-8, weight_decay=config.train.weight_decay)
     return fit(model, state, None, train_dl, max_node_number=config.dataset.max_node_num, max_epoch=config.train.max_epoch,
                config=config, save_interval=config.train.save_interval, sample_interval=config.train.sample_interval,
-               sigma_length=len(config.train.sigmas), sample_from_sigma_delta=0.0, test_dl=test_dl)
+               sigma_length=len(config.train.sigmas), sample_from_sigma_delta=0.0, test_dl=test_dl,
+               resume=getattr(args, "resume", None) or None)
 
 
 def main(argv=None):

@@ -39,7 +39,7 @@ def loss_func_kld(score_list, train_noise_adj_b, train_adj_b, grad_log_q_noise_l
 
 
 def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20, config=None, save_interval=50,
-        sample_interval=1, test_dl=None, eval_set=None, **_ignored):
+        sample_interval=1, test_dl=None, eval_set=None, resume=None, **_ignored):
     """reference ppgn_vlb.py:127-331; epoch bookkeeping shared with ppgn_simple.fit, step = engine.train_step_vlb."""
     T = config.num_levels[0]
     seed = int(getattr(config, "seed", 0))
@@ -58,10 +58,10 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
         loss, _ = ops.loss_vlb(model.infer(A_t, mask, sched[:, 0]), A_t, adj, sched, mask, want_grad=False)
         return loss
 
-    return _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, draw, step_fn)
+    return _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, draw, step_fn, resume)
 
 
-def _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, draw, step_fn):
+def _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, draw, step_fn, resume=None):
     import time
     dist, rank, world = _simple._dist()
     if isinstance(optimizer, engine.FlatState):
@@ -70,9 +70,12 @@ def _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, s
         g = optimizer.param_groups[0]
         state = engine.FlatState(model, lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'], weight_decay=g['weight_decay'])
     lr0, gamma = state.lr, config.train.lr_dacey
+    first_epoch = 0
+    if resume is not None:
+        lr0, gamma, first_epoch = _simple._resume(resume, model, state, config, lr0, gamma)
     best_score, best_score_loss = np.inf, np.inf
     counters = {"offset": 0, "gid": 0, "draw": draw}
-    for epoch in range(max_epoch):
+    for epoch in range(first_epoch, max_epoch):
         t0 = time.time()
         model.train()
         tr = _simple._epoch_loop(model, state, train_dl, config, step_fn, True, epoch, counters)
@@ -114,7 +117,7 @@ def train_main(config, args):
     state = engine.FlatState(model, lr=config.train.lr_init, betas=(0.9, 0.999), eps=1e-8, weight_decay=config.train.weight_decay)
     return fit(model, state, None, train_dl, max_node_number=config.dataset.max_node_num, max_epoch=config.train.max_epoch,
                config=config, save_interval=config.train.save_interval, sample_interval=config.train.sample_interval,
-               test_dl=test_dl)
+               test_dl=test_dl, resume=getattr(args, "resume", None) or None)
 
 
 def main(argv=None):

@@ -25,6 +25,7 @@ def parse_arguments(default_config="train.yaml", argv=None):
     parser.add_argument('-l', '--log_level', type=str, default='INFO',
                         help="Logging Level, one of: DEBUG, INFO, WARNING, ERROR, CRITICAL")
     parser.add_argument('-m', '--comment', type=str, default="", help="A single line comment for the experiment")
+    parser.add_argument('--resume', type=str, default="", help="checkpoint (.pth written by this package) to continue training from")
     return parser.parse_args(argv)
 
 

@@ -260,3 +260,49 @@ def test_train_main_and_sample_main_end_to_end(tmp_path, monkeypatch, which):
         assert np.isfinite(ckp["train_loss"])
     res = smod.sample_main(cfg, cfg.model_save_dir, 1, 4)
     assert "degree" in res and np.isfinite(res["degree"])
+
+
+def test_resume_continues_training(tmp_path, monkeypatch):
+    """Three epochs in one go == two epochs, checkpoint, resume for the third (same numpy seed stream for the sigma draws is
+    not kept across processes by the reference either, so the check is on the bookkeeping: weights and Adam moments are
+    restored exactly, the step counter / epoch / learning-rate schedule continue)."""
+    import discrete_dppm_graphs_amd.ppgn_simple as ps
+    from discrete_dppm_graphs_amd.utils.easydict import EasyDict
+    from discrete_dppm_graphs_amd.utils import arg_helper
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(16)
+    os.makedirs("data")
+    adjs = rand_graphs(rng, 20, 10)
+    np.savez(os.path.join("data", "toy.npz"), adjs=adjs, sizes=(adjs.sum(-1) > 0).sum(-1))
+    open(os.path.join("data", "toy.txt"), "w").write("toy")
+
+    def make_cfg(max_epoch):
+        cfg = EasyDict(exp_dir="exp", exp_name="toy", seed=1234, dataset=dict(dataset_size=20, max_node_num=10, name="toy"),
+                       model=dict(name="ppgn"), test=dict(batch_size=4, split=0.2),
+                       train=dict(batch_size=8, lr_dacey=0.9, lr_init=0.01, max_epoch=max_epoch, sample_interval=100, save_interval=1,
+                                  weight_decay=0.0),
+                       eval_from=1000, samplesize=8, finalinterval=1000, num_layers=2, hidden=16, hidden_final=16, dropout=1e-6, n_nodes=10,
+                       normalization="instance", noise_mlp=False, num_levels=[4], noisetype="switched")
+        arg_helper.process_config(cfg)
+        return cfg
+    cfg = make_cfg(2)
+    state = ps.train_main(cfg, types.SimpleNamespace(log_level="INFO", comment="a", resume=""))
+    import shutil
+    path = os.path.join(str(tmp_path), "epoch1.pth")      # the second run writes its own checkpoints over the first run's
+    shutil.copy(os.path.join(cfg.model_save_dir, "toy.pth"), path)
+    ckp = torch.load(path, weights_only=True)
+    assert ckp["epoch"] == 1 and ckp["optimizer_state_dict"]["step"] == 4
+    flat_before, m_before = state.flat.clone(), state.exp_avg.clone()
+
+    cfg2 = make_cfg(3)
+    state2 = ps.train_main(cfg2, types.SimpleNamespace(log_level="INFO", comment="b", resume=path))
+    assert state2.step_count == 6                              # 4 restored + one more epoch of 2 steps
+    assert abs(state2.lr - 0.01 * 0.9 ** 3) < 1e-12            # schedule continued, not restarted
+    assert not torch.equal(state2.flat, flat_before)           # it trained on
+    # restoring alone reproduces weights and moments bit for bit
+    from discrete_dppm_graphs_amd.utils.loading_utils import get_score_model
+    from discrete_dppm_graphs_amd import engine
+    model3 = get_score_model(cfg2)
+    state3 = engine.FlatState(model3, lr=0.01)
+    ps._resume(path, model3, state3, cfg2, 0.01, 0.9)
+    assert torch.equal(state3.flat, flat_before) and torch.equal(state3.exp_avg, m_before) and state3.step_count == 4
