@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="graphs per GPU")
     ap.add_argument("--train-steps", type=int, default=3, help="timed optimizer steps for the training figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+                    help="matrix arithmetic of the sampler's H=128 kernels (include/dppm_hip.h DPPM_PREC_*)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -103,6 +105,7 @@ def main():
     torch.manual_seed(1234)
     model = Powerful(num_layers=L, hidden=H, hidden_final=H, n_nodes=N, normalization="instance", adj_out=True,
                      input_features=2, dropout_p=1e-6).cuda().eval()
+    model.precision = args.precision
     rng = np.random.default_rng(1234 + rank)
     flags = torch.ones(B, N, device="cuda")
     seed = 1234

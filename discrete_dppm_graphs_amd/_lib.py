@@ -10,7 +10,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdppm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+
+# DPPM_PREC_* of include/dppm_hip.h
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
 
 c_f32p = C.c_void_p     # device pointers travel as integers
 c_f64p = C.c_void_p
@@ -51,7 +54,7 @@ SIGNATURES = {
                                         C.c_void_p, C.c_size_t, c_stream]),
     "dppm_ppgn_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "dppm_ppgn_forward": (C.c_int, [C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, C.c_void_p,
-                                    C.c_size_t, C.c_int, c_stream]),
+                                    C.c_size_t, C.c_int, C.c_int, c_stream]),
     "dppm_ppgn_backward": (C.c_int, [C.POINTER(PpgnParams), C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                      c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "dppm_plane_matmul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
@@ -59,7 +62,7 @@ SIGNATURES = {
     "dppm_linear_fwd": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_long, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_long,
                                   C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dppm_mlp_pair_fwd": (C.c_int, [c_f32p, C.c_long, C.POINTER(PpgnLayer), C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
-                                    C.c_int, c_stream]),
+                                    C.c_int, C.c_int, c_stream]),
     "dppm_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "dppm_linear_wgrad": (C.c_int, [c_f32p, C.c_long, c_f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                     c_f32p, C.c_void_p, C.c_size_t, c_stream]),

@@ -67,4 +67,4 @@ extern "C" int dppm_prof_end(double* ms_per_class, double* work_per_class, long*
 }
 
 extern "C" const char* dppm_last_error(void) { return dppm::error_buffer(); }
-extern "C" int dppm_abi_version(void) { return 1; }
+extern "C" int dppm_abi_version(void) { return 2; }

@@ -11,6 +11,7 @@
 // so the reference's permutes and cats never cost a byte.  All GEMMs run on v_mfma_f32_32x32x2_f32 (dppm_gemm.h).
 #include "dppm_gemm.h"
 #include "dppm_wstat.h"
+#include "dppm_wsplit.h"
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
 #include <cstdlib>
@@ -324,6 +325,14 @@ inline bool use_wstat(int H) {
   return H == WS_H && !off;
 }
 
+// weight-stationary Linear in the requested arithmetic (include/dppm_hip.h DPPM_PREC_*)
+inline int ws_lin_p(const WsArgs& a, int nsrc, bool trans, int prec, hipStream_t st) {
+  if (prec == DPPM_PREC_BF16X3) return w3_lin<3>(a, nsrc, trans, st);
+  if (prec == DPPM_PREC_BF16) return w3_lin<1>(a, nsrc, trans, st);
+  return ws_lin(a, nsrc, trans, st);
+}
+inline bool valid_prec(int prec) { return prec == DPPM_PREC_F32 || prec == DPPM_PREC_BF16X3 || prec == DPPM_PREC_BF16; }
+
 GemmArgs base_args() {
   GemmArgs a{};
   a.nseg = 1; a.nsplit = 1; a.kchunk = 0; a.scale_div = 1; a.mul_div = 1;
@@ -367,7 +376,7 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
 
 // m1, m2: Linear -> LeakyReLU -> Linear, then * mask   (model/ppgn.py:58-59)
 int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long x_bs, const float* maskp, float* o1, float* o2,
-             float* hid1, float* hid2, bool save_hid) {
+             float* hid1, float* hid2, bool save_hid, int prec) {
   const long hs = (long)H * c.P;
   if (use_wstat(H)) {   // weight-stationary fused pair: hidden activations stay in LDS unless training
     WsArgs wa{};
@@ -380,7 +389,9 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
       j.X = x; j.x_bs = x_bs; j.W1 = w0[k]; j.W2 = w1[k]; j.ldw1 = H; j.ldw2 = H; j.b1 = b0[k]; j.b2 = b1[k];
       j.Mid = save_hid ? hid[k] : nullptr; j.mid_bs = hs; j.Y = out[k]; j.y_bs = hs;
     }
-    return ws_mlp_forward(wa, save_hid, c.st);
+    if (!save_hid && prec == DPPM_PREC_BF16X3) return w3_mlp_forward<3>(wa, c.st);
+    if (!save_hid && prec == DPPM_PREC_BF16) return w3_mlp_forward<1>(wa, c.st);
+    return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
   }
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, false, hid1, hs, H}, nullptr, q.m1_b1, 0, maskp, nullptr, 0, o1, hs, false));
@@ -489,14 +500,15 @@ extern "C" int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float
 }
 
 extern "C" int dppm_mlp_pair_fwd(const float* X, long x_bs, const dppm_ppgn_layer* q, int H, const float* maskp, float* o1, float* o2,
-                                 float* hid1, float* hid2, int B, int P, void* stream) {
+                                 float* hid1, float* hid2, int B, int P, int precision, void* stream) {
   DPPM_REQUIRE(X && q && o1 && o2, "dppm_mlp_pair_fwd: null pointer");
   DPPM_REQUIRE(q->m1_w0 && q->m1_b0 && q->m1_w1 && q->m1_b1 && q->m2_w0 && q->m2_b0 && q->m2_w1 && q->m2_b1, "dppm_mlp_pair_fwd: null weight");
   DPPM_REQUIRE(H >= 4 && H % 4 == 0 && B > 0 && P > 0 && P % 4 == 0, "dppm_mlp_pair_fwd: H=%d B=%d P=%d", H, B, P);
   DPPM_REQUIRE((hid1 == nullptr) == (hid2 == nullptr), "dppm_mlp_pair_fwd: pass both hidden buffers or none");
   DPPM_REQUIRE(H == WS_H || hid1, "dppm_mlp_pair_fwd: H != 128 needs hid1/hid2 as scratch");
   DPPM_REQUIRE(aligned16(X) && aligned16(o1) && aligned16(o2) && x_bs % 4 == 0, "dppm_mlp_pair_fwd: planes must be 16-byte aligned");
-  return mlp_pair(Geo{B, P, as_stream(stream)}, *q, H, X, x_bs, maskp, o1, o2, hid1, hid2, hid1 != nullptr);
+  DPPM_REQUIRE(valid_prec(precision), "dppm_mlp_pair_fwd: precision=%d", precision);
+  return mlp_pair(Geo{B, P, as_stream(stream)}, *q, H, X, x_bs, maskp, o1, o2, hid1, hid2, hid1 != nullptr, precision);
 }
 
 extern "C" size_t dppm_linear_wgrad_workspace_bytes(int M, int Nw, int B, int P) {
@@ -526,8 +538,11 @@ extern "C" int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, flo
 }
 
 extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B,
-                                 int N, float* logits, void* workspace, size_t workspace_bytes, int training, void* stream) {
+                                 int N, float* logits, void* workspace, size_t workspace_bytes, int training, int precision,
+                                 void* stream) {
   DPPM_TRY(check_params(pr, "dppm_ppgn_forward"));
+  DPPM_REQUIRE(valid_prec(precision), "dppm_ppgn_forward: precision=%d", precision);
+  const int prec = training ? DPPM_PREC_F32 : precision;   // gradients are taken of the exact-float32 forward
   DPPM_REQUIRE(A && mask && sigma && logits && workspace, "dppm_ppgn_forward: null pointer");
   DPPM_REQUIRE(B > 0 && N > 0, "dppm_ppgn_forward: B=%d N=%d must be positive", B, N);
   DPPM_REQUIRE(((uintptr_t)workspace & 255) == 0, "dppm_ppgn_forward: workspace must be 256-byte aligned");
@@ -559,7 +574,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     float* o2 = training ? c.at(w.o2) + (size_t)l * w.S : c.at(w.tmp[2]);
     float* mm = training ? c.at(w.mm) + (size_t)l * w.S : c.at(w.tmp[0]);
     float* y = c.at(w.tmp[3]);
-    DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0));
+    DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
     DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
@@ -569,7 +584,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       WsJob& j = wa.job[0];
       j.X = mm; j.x_bs = hs; j.X2 = x; j.x2_bs = x_bs; j.W1 = q.m4_w; j.W2 = q.m4_w + H; j.ldw1 = 2 * H; j.ldw2 = 2 * H; j.b1 = q.m4_b;
       j.Y = y; j.y_bs = hs;
-      DPPM_TRY(ws_lin(wa, 2, false, c.st));
+      DPPM_TRY(ws_lin_p(wa, 2, false, prec, c.st));
     } else {
       LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
@@ -593,7 +608,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       j.Y = c.at(w.R); j.y_bs = hs;
       if (l0 == 0) { j.b1 = pr->cat_b; wa.side = cat; wa.side_bs = cat_bs; wa.wside = pr->cat_w; wa.ldws = w.CT; }
       else j.accumulate = 1;
-      DPPM_TRY(ws_lin(wa, ns, false, c.st));
+      DPPM_TRY(ws_lin_p(wa, ns, false, prec, c.st));
     }
   } else {
     DPPM_TRY(linear(c, H, LinArgs{pr->cat_w, w.CT, false, cat, cat_bs, w.CT}, nullptr, pr->cat_b, 0, nullptr, nullptr, 0, c.at(w.R), hs, false));
@@ -604,7 +619,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     wa.njobs = 1; wa.B = B; wa.P = P; wa.act = 1;
     WsJob& j = wa.job[0];
     j.X = c.at(w.R); j.x_bs = hs; j.W1 = pr->after_w; j.ldw1 = H; j.b1 = pr->after_b; j.Y = c.at(w.act); j.y_bs = hs;
-    DPPM_TRY(ws_lin(wa, 1, false, c.st));
+    DPPM_TRY(ws_lin_p(wa, 1, false, prec, c.st));
   } else {
     DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, false, c.at(w.R), hs, H}, nullptr, pr->after_b, 1, nullptr, nullptr, 0, c.at(w.act), hs, false));
   }
@@ -617,6 +632,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
                                   const float* sigma, int B, int N, const float* dlogits, float* dsigma, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   (void)A; (void)mask; (void)sigma;
+  const int prec = DPPM_PREC_F32;
   DPPM_TRY(check_params(pr, "dppm_ppgn_backward(params)"));
   DPPM_TRY(check_params(gr, "dppm_ppgn_backward(grads)"));
   DPPM_REQUIRE(dlogits && workspace, "dppm_ppgn_backward: null pointer");
@@ -658,7 +674,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     wa.njobs = 1; wa.B = B; wa.P = P;
     WsJob& j = wa.job[0];
     j.X = dz; j.x_bs = hs; j.W1 = pr->after_w; j.ldw1 = H; j.Y = dh; j.y_bs = hs; j.accumulate = 1;
-    DPPM_TRY(ws_lin(wa, 1, true, c.st));
+    DPPM_TRY(ws_lin_p(wa, 1, true, prec, c.st));
   } else {
     DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, true, dz, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dh, hs, true));
   }
@@ -679,7 +695,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
         j.X = dh; j.x_bs = hs; j.W1 = pr->cat_w + 2 + (size_t)(j0 + k) * H; j.ldw1 = w.CT;
         j.Y = dcat + (size_t)(2 + (j0 + k) * H) * P; j.y_bs = cat_bs;
       }
-      DPPM_TRY(ws_lin(wa, 1, true, c.st));
+      DPPM_TRY(ws_lin_p(wa, 1, true, prec, c.st));
     }
   } else {
     DPPM_TRY(linear(c, w.CT, LinArgs{pr->cat_w, w.CT, true, dh, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dcat, cat_bs, false));
@@ -711,7 +727,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       j0.X = dy; j0.x_bs = hs; j0.W1 = q.m4_w; j0.ldw1 = 2 * H; j0.Y = dmm; j0.y_bs = hs;
       WsJob& j1 = wa.job[1];
       j1.X = dy; j1.x_bs = hs; j1.W1 = q.m4_w + H; j1.ldw1 = 2 * H; j1.Y = dx; j1.y_bs = dx_bs; j1.accumulate = l != 0;
-      DPPM_TRY(ws_lin(wa, 1, true, c.st));
+      DPPM_TRY(ws_lin_p(wa, 1, true, prec, c.st));
     } else {
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dmm, hs, false));
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));

@@ -1,0 +1,448 @@
+// Weight-stationary H = 128 linears on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, 16x the f32 MFMA rate).
+//
+// Operands stay float32 in HBM.  While a tile is staged into LDS every value x is split into bf16 pieces
+//   x = hi + lo + r,  hi = bf16(x) (round to nearest even),  lo = bf16(x - hi),  |r| <= 2^-17 |x|
+// and a product is evaluated as  x w ~= hi_x hi_w + hi_x lo_w + lo_x hi_w  (NS = 3; the dropped lo_x lo_w term is
+// <= 2^-16 |x w|), accumulated in float32 by the MFMA.  A K = 128 Linear then agrees with the exact-f32 kernels of
+// dppm_wstat.h to ~1e-5 of the result's magnitude, at 3/16 of their matrix time: the kernels become HBM-bound.
+// NS = 1 keeps the hi pieces only (plain bf16 operands, f32 accumulate; tolerance stated in DESIGN.md).
+//
+// Same organisation as dppm_wstat.h (persistent workgroups, wave w owns output channels 16w .. 16w+15, weights
+// register-resident for the whole launch, 64-position tiles) with these differences:
+//   - a staged tile is an image [64 positions][128 k] of bf16 (k contiguous: a lane's MFMA fragment, 8 consecutive k
+//     of one position, is one ds_read_b128), one image for hi and one for lo.  16-byte chunk c of position p lives at
+//     chunk c ^ f(p), f(p) = (p & 15) ^ ((p >> 4) & 3): the fragment reads (16 lanes = 16 consecutive positions) and
+//     the staging writes (16 lanes = positions 4 apart, 8 bytes each, two lanes per chunk) are both conflict-free;
+//   - staging thread (q, cg) moves channels 4cg .. 4cg+3 of positions 4q .. 4q+3 (four float4 global loads of 256
+//     contiguous bytes per 16 lanes) and writes, per position, 4 consecutive k as 8 bytes per image;
+//   - in the fused MLP the first product is issued as D = W * X (lane gets 4 consecutive CHANNELS of one position =
+//     8 bytes of the hidden image), the second as D = H^T * W^T (lane gets 4 consecutive POSITIONS of one channel =
+//     one 16-byte global store), so neither result needs a transpose.
+#pragma once
+#include "dppm_wstat.h"
+
+namespace dppm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+
+constexpr int W3_IMG = WS_TP * WS_H * 2;   // bytes of one bf16 image of a tile (16 KB)
+
+__device__ __forceinline__ unsigned w3_pack(float a, float b) {   // (bf16(a), bf16(b)) -> one dword, a in the low half
+  const floatx2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+template <int NS>
+__device__ __forceinline__ void w3_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = w3_pack(x0, x1);
+  if (NS > 1) lo = w3_pack(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+__device__ __forceinline__ floatx4 w3_mfma(const uintx4& a, const uintx4& b, const floatx4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// a lane's weights of output channel ch as four K = 32 fragments: element e of fragment s is W[ch][32 s + 8 g + e]
+// (TRANS: W[32 s + 8 g + e][ch])
+template <int NS, bool TRANS>
+__device__ __forceinline__ void w3_load_w(uintx4 (&wh)[4], uintx4 (&wl)[4], const float* __restrict__ W, int ldw, int ch, int g) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[8];
+    if (TRANS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(32 * s + 8 * g + e) * ldw + ch];
+    } else {
+      const float* p = W + (size_t)ch * ldw + 32 * s + 8 * g;
+      if ((((uintptr_t)p) & 15) == 0) {
+        const float4 q0 = reinterpret_cast<const float4*>(p)[0], q1 = reinterpret_cast<const float4*>(p)[1];
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned h, l = 0;
+      w3_split2<NS>(v[2 * e], v[2 * e + 1], h, l);
+      wh[s][e] = h;
+      wl[s][e] = l;
+    }
+  }
+}
+
+// global tile (128 channels x 64 positions) -> registers: thread (q = tid & 15, cg = tid >> 4) takes channels 4cg + v,
+// positions 4q .. 4q+3.  o0 = 4 (tid >> 4) * P + 4 (tid & 15).
+__device__ __forceinline__ void w3_tile_load(float4 (&r)[4], const float* __restrict__ Xt, unsigned P, unsigned o0, bool ok) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const float* Xv = Xt + (size_t)v * P;
+    r[v] = ok ? *reinterpret_cast<const float4*>(Xv + o0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// registers -> the bf16 image(s) of the tile
+template <int NS>
+__device__ __forceinline__ void w3_put4(char* __restrict__ T, unsigned off, float x0, float x1, float x2, float x3) {
+  unsigned h01, l01 = 0, h23, l23 = 0;
+  w3_split2<NS>(x0, x1, h01, l01);
+  w3_split2<NS>(x2, x3, h23, l23);
+  *reinterpret_cast<uint2*>(T + off) = make_uint2(h01, h23);
+  if (NS > 1) *reinterpret_cast<uint2*>(T + W3_IMG + off) = make_uint2(l01, l23);
+}
+template <int NS>
+__device__ __forceinline__ void w3_tile_store4(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, int tid) {
+  const unsigned q = tid & 15, cg = tid >> 4;
+  const unsigned base = (4 * q) * 256 + (cg & 1) * 8;
+  const unsigned kc = (cg >> 1) ^ (4 * (q & 3)) ^ (q >> 2);   // swizzled chunk of position 4q; position 4q + e: kc ^ e
+  w3_put4<NS>(T, base + ((kc ^ 0) << 4), r0.x, r1.x, r2.x, r3.x);
+  w3_put4<NS>(T, base + 256 + ((kc ^ 1) << 4), r0.y, r1.y, r2.y, r3.y);
+  w3_put4<NS>(T, base + 512 + ((kc ^ 2) << 4), r0.z, r1.z, r2.z, r3.z);
+  w3_put4<NS>(T, base + 768 + ((kc ^ 3) << 4), r0.w, r1.w, r2.w, r3.w);
+}
+template <int NS>
+__device__ __forceinline__ void w3_tile_store(const float4 (&r)[4], char* __restrict__ T, int tid) {
+  w3_tile_store4<NS>(r[0], r[1], r[2], r[3], T, tid);
+}
+// one tile in flight: plain members (no array) so that the set provably stays in registers
+struct W3Pre { float4 a, b, c, d; float m; };
+
+// per-lane byte offsets of the fragment (position 16 j + ci, k = 32 s + 8 g ..): aj[j] ^ (s << 6)
+// (chunk (4s | g) ^ ci ^ j: bits 2-3 are s ^ (ci >> 2), folded into aj as (ci >> 2) << 6, so s enters as one XOR)
+struct W3Addr { unsigned aj[4]; };
+__device__ __forceinline__ W3Addr w3_addr(int ci, int g) {
+  W3Addr a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a.aj[j] = (16 * j + ci) * 256 + ((ci >> 2) << 6) + ((g ^ (ci & 3) ^ j) << 4);
+  return a;
+}
+__device__ __forceinline__ unsigned w3_off(const W3Addr& a, int j, int s) { return a.aj[j] ^ (unsigned)(s << 6); }
+
+// acc[j] += X-tile(positions 16 j ..) x W-slice over K = 128.  W_IS_A: D = W X (lane: 4 channels of one position);
+// else D = X^T W^T (lane: 4 positions of one channel).
+template <int NS, bool W_IS_A>
+__device__ __forceinline__ void w3_mma4(floatx4 (&acc)[4], const uintx4 (&wh)[4], const uintx4 (&wl)[4], const char* __restrict__ T,
+                                        const W3Addr& ad) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned off = w3_off(ad, j, s);
+      const uintx4 xh = *reinterpret_cast<const uintx4*>(T + off);
+      if (NS > 1) {
+        const uintx4 xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
+        acc[j] = W_IS_A ? w3_mfma(wh[s], xl, acc[j]) : w3_mfma(xl, wh[s], acc[j]);
+        acc[j] = W_IS_A ? w3_mfma(wl[s], xh, acc[j]) : w3_mfma(xh, wl[s], acc[j]);
+      }
+      acc[j] = W_IS_A ? w3_mfma(wh[s], xh, acc[j]) : w3_mfma(xh, wh[s], acc[j]);
+    }
+  }
+}
+
+// Y (+)= epilogue(sum_s W_s X_s + b): one or two 128-channel sources, optional rank-2 side input, LeakyReLU, mask.
+template <int NS, int NSRC, bool TRANS>
+__global__ __launch_bounds__(WS_THREADS, 4) void w3_lin_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * wave + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+
+  uintx4 wh[NSRC][4], wl[NSRC][4];
+  w3_load_w<NS, TRANS>(wh[0], wl[0], J.W1, J.ldw1, ch, g);
+  if (NSRC == 2) w3_load_w<NS, TRANS>(wh[NSRC - 1], wl[NSRC - 1], J.W2, J.ldw2, ch, g);
+  const float bv = J.b1 ? J.b1[ch] : 0.f;
+
+  const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);
+  const int oc = 4 * (tid & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+  const W3Addr ad = w3_addr(ci, g);
+
+  // prefetch set in named registers; loads are unconditional (clamped) so that the compiler's counted waits stay exact
+  W3Pre pre;
+  auto issue = [&](const float* __restrict__ Xt, bool in) {
+    const float* p = Xt + (in ? o0 : 0u);
+    pre.a = *reinterpret_cast<const float4*>(p);
+    pre.b = *reinterpret_cast<const float4*>(p + (size_t)P);
+    pre.c = *reinterpret_cast<const float4*>(p + (size_t)2 * P);
+    pre.d = *reinterpret_cast<const float4*>(p + (size_t)3 * P);
+  };
+  auto land = [&](char* T, bool in) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, T, tid);
+  };
+  int t = who.rank;
+  if (t >= ntiles) return;   // whole workgroup, before any barrier
+  {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    issue(J.X + (size_t)b * J.x_bs + p0, p0 + oc < P);
+    land(smem3, p0 + oc < P);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (; t < ntiles; t += who.per_job) {
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const int tn = t + who.per_job < ntiles ? t + who.per_job : t;   // past the end: re-read this tile (never consumed)
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      // the tile that follows this one in the stream: the next source of the same positions, or source 0 of the next tile
+      const bool last = (s == NSRC - 1);
+      bool in;
+      if (last) {
+        const int bn = __builtin_amdgcn_readfirstlane(tn / tpp), pn = __builtin_amdgcn_readfirstlane((tn % tpp) * WS_TP);
+        in = pn + oc < P;
+        issue(J.X + (size_t)bn * J.x_bs + pn, in);
+      } else {
+        in = p0 + oc < P;
+        issue(J.X2 + (size_t)b * J.x2_bs + p0, in);
+      }
+      w3_mma4<NS, false>(acc, wh[s], wl[s], smem3 + cur * NIMG * W3_IMG, ad);
+      land(smem3 + (cur ^ 1) * NIMG * W3_IMG, in);
+      if (last) {
+        if (a.side) {   // uniform branch
+          const float s0 = a.wside[(size_t)ch * a.ldws], s1 = a.wside[(size_t)ch * a.ldws + 1];
+          const float* St = a.side + (size_t)b * a.side_bs + p0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((int)m0 + 16 * j < P - p0) {
+              const float4 x0 = *reinterpret_cast<const float4*>(St + m0 + 16 * j);
+              const float4 x1 = *reinterpret_cast<const float4*>(St + P + m0 + 16 * j);
+              acc[j][0] += s0 * x0.x + s1 * x1.x; acc[j][1] += s0 * x0.y + s1 * x1.y;
+              acc[j][2] += s0 * x0.z + s1 * x1.z; acc[j][3] += s0 * x0.w + s1 * x1.w;
+            }
+          }
+        }
+        ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
+                     J.accumulate != 0);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused MLP  out = (W2 LeakyReLU(W1 X + b1) + b2) * mask  (model/ppgn.py:58-59), inference form (the hidden tile never
+// leaves LDS).  One 16-wave workgroup per CU with the two stages on DIFFERENT waves: waves 0-7 hold W1, compute the
+// hidden tile of tile i (X image -> H image) and stage tile i+1 (global loads issued before the MFMAs of tile i, landed
+// after them); waves 8-15 hold W2 and turn the hidden tile of tile i-1 into the output.  One barrier per tile; X and H
+// images are double-buffered so neither stage waits for the other.
+// Why the roles are split: with both stages on one wave (as in dppm_wstat.h) the bf16 stages are too short to cover the
+// prefetch and store latencies, and a wave that both prefetches and stores must drain its fresh stores at every counted
+// wait for the prefetch (one in-order counter for loads and stores).  Here the loading waves never store and the
+// storing waves never wait: measured 1.39 ms (f32) -> 0.84 (one wave, both stages) -> 0.48 ms per MLP pair launch.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int W3M_THREADS = 1024;
+
+// two position groups (16 jb + ci, 16 (jb+1) + ci) x the wave's 16 channels over K = 128
+template <int NS, bool W_IS_A>
+__device__ __forceinline__ void w3_mma2(floatx4 (&acc)[2], const uintx4 (&wh)[4], const uintx4 (&wl)[4], const char* __restrict__ T,
+                                        const W3Addr& ad, int jb) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned off = w3_off(ad, jb + j, s);
+      const uintx4 xh = *reinterpret_cast<const uintx4*>(T + off);
+      if (NS > 1) {
+        const uintx4 xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
+        acc[j] = W_IS_A ? w3_mfma(wh[s], xl, acc[j]) : w3_mfma(xl, wh[s], acc[j]);
+        acc[j] = W_IS_A ? w3_mfma(wl[s], xh, acc[j]) : w3_mfma(xh, wl[s], acc[j]);
+      }
+      acc[j] = W_IS_A ? w3_mfma(wh[s], xh, acc[j]) : w3_mfma(xh, wh[s], acc[j]);
+    }
+  }
+}
+
+// DEPTH = tiles in flight per staging wave (1: 16 registers, 2: 32): the short bf16 stages need 2, the 3-MFMA stages of the
+// split form cover the latency with 1 (and have no registers to spare).
+template <int NS, int DEPTH>
+__global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int BUF = NIMG * W3_IMG;
+  char* Xs = smem3;                       // [2][NIMG] images
+  char* Hs = smem3 + 2 * BUF;             // [2][NIMG] images
+  float* Ms = reinterpret_cast<float*>(smem3 + 4 * BUF);   // [4][64] mask rows: tile i is written in iteration i-1 and read in i+1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 3, w8 = wave & 7;
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * w8 + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+  if (who.rank >= ntiles) return;   // whole workgroup, before any barrier
+
+  uintx4 wh[4], wl[4];
+  w3_load_w<NS, false>(wh, wl, role ? J.W2 : J.W1, role ? J.ldw2 : J.ldw1, ch, g);
+  float bv[4];   // stage 1: biases of channels 16 w8 + 4 g + r; stage 2: bias of channel ch in bv[0]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = role ? (J.b2 ? J.b2[ch] : 0.f) : (J.b1 ? J.b1[16 * w8 + 4 * g + r] : 0.f);
+
+  const unsigned o0 = (unsigned)(4 * ((tid & 511) >> 4)) * P + 4 * (tid & 15);   // staging (waves 0-7): channels 4cg.., positions 4q..
+  const int oc = 4 * (tid & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+  const W3Addr ad = w3_addr(ci, g);
+  // stage 1 result slot in the hidden image: position 16 j + ci, k = 16 w8 + 4 g .. +3 (chunk 2 w8 + (g >> 1), half g & 1)
+  const unsigned hbase = ci * 256 + (g & 1) * 8, hchunk = (2 * w8 + (g >> 1)) ^ ci;
+
+  // tiles of this workgroup: t_i = rank + i * per_job, i < nloc (>= 1).
+  // Every global load below is UNCONDITIONAL straight-line code (indices clamped instead of predicated): a load inside
+  // a lane- or loop-dependent branch makes the compiler drain the whole queue (s_waitcnt vmcnt(0)) at the join, which
+  // serialises the prefetch with the compute.
+  const int nloc = (ntiles - who.rank + who.per_job - 1) / who.per_job;
+  const float* maskp = a.maskp;
+  // Only the stage-1 waves stage tiles: their queue then holds loads only, so the counted waits the compiler emits are
+  // exact.  (A wave that also stores would have to drain its just-issued stores before every landing.)
+  auto issue = [&](int i, W3Pre& pre) {   // global loads of tile min(i, nloc-1) into a prefetch register set
+    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const float* Xt = J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);   // ragged last tile: re-read in-range data, zeroed when landed
+    pre.a = *reinterpret_cast<const float4*>(Xt);
+    pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+    pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+    pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+    if (maskp) pre.m = maskp[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
+  };
+  auto land = [&](int i, const W3Pre& pre) {   // register set -> images of buffer i & 1, mask row i & 3
+    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const bool in = p0 + oc < P;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs + (i & 1) * BUF, tid);
+    if (tid < 64) Ms[(i & 3) * 64 + tid] = (p0 + lane < P) ? pre.m : 0.f;
+  };
+  // one iteration: stage 1 of tile i and stage 2 of tile i-1; tile i + AHEAD is requested into (pi, mi) before the MFMAs,
+  // tile i+1 is landed from (pl, ml) after them
+  auto step = [&](int i, W3Pre& pi, const W3Pre& pl) {
+    if (role == 0) {
+      issue(i + DEPTH, pi);
+      if (i < nloc) {
+        char* Hb = Hs + (i & 1) * BUF;
+#pragma unroll
+        for (int jb = 0; jb < 4; jb += 2) {
+          floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+          w3_mma2<NS, true>(acc, wh, wl, Xs + (i & 1) * BUF, ad, jb);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            unsigned h01, l01 = 0, h23, l23 = 0;
+            w3_split2<NS>(ws_leaky(acc[j][0] + bv[0]), ws_leaky(acc[j][1] + bv[1]), h01, l01);
+            w3_split2<NS>(ws_leaky(acc[j][2] + bv[2]), ws_leaky(acc[j][3] + bv[3]), h23, l23);
+            const unsigned off = hbase + (jb + j) * 4096 + ((hchunk ^ (jb + j)) << 4);
+            *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
+            if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
+          }
+        }
+      }
+      land(i + 1, pl);
+    } else if (i >= 1) {
+      const int t = who.rank + (i - 1) * who.per_job;
+      const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+      const float* Mb = Ms + ((i - 1) & 3) * 64;
+      float* Yt = J.Y + (size_t)b * J.y_bs + p0;
+      const int lim = P - p0;
+#pragma unroll
+      for (int jb = 0; jb < 4; jb += 2) {
+        floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        w3_mma2<NS, false>(acc, wh, wl, Hs + ((i - 1) & 1) * BUF, ad, jb);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int pj = (int)m0 + 16 * (jb + j);
+          if (pj < lim) {
+            float4 v = ws_f4(acc[j]);
+            v.x += bv[0]; v.y += bv[0]; v.z += bv[0]; v.w += bv[0];
+            if (maskp) {
+              const float4 m = *reinterpret_cast<const float4*>(Mb + pj);
+              v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            }
+            *reinterpret_cast<float4*>(Yt + r0 + 16 * (jb + j)) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  W3Pre preA, preB;
+  preA.m = preB.m = 1.f;
+  if (role == 0) {
+    issue(0, preA);
+    land(0, preA);
+    if (DEPTH == 2) issue(1, preB);
+  }
+  __syncthreads();
+  if (DEPTH == 1) {
+    for (int i = 0; i <= nloc; ++i) step(i, preA, preA);
+  } else {   // tile k travels in set k & 1
+    for (int i = 0;;) {
+      step(i, preA, preB);
+      if (++i > nloc) break;
+      step(i, preB, preA);
+      if (++i > nloc) break;
+    }
+  }
+}
+
+template <int NS> inline size_t w3m_lds() { return (size_t)(NS > 1 ? 8 : 4) * W3_IMG + 4 * 64 * sizeof(float); }
+
+template <int NS, int DEPTH = (NS > 1 ? 1 : 2)>
+inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "w3_mlp_forward"));
+  for (int i = 0; i < a.njobs; ++i) {
+    if (!a.job[i].W2) return fail(DPPM_E_INVALID, "w3_mlp_forward: job %d lacks its second matrix", i);
+    if (a.job[i].accumulate) return fail(DPPM_E_UNSUPPORTED, "w3_mlp_forward: accumulate is not provided");
+  }
+  static bool set = false;
+  const size_t lds = w3m_lds<NS>();
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(w3_mlp_kernel<NS, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "w3_mlp_forward: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    set = true;
+  }
+  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
+  long slots = 32 / a.njobs;                       // one workgroup per CU: 32 per XCD
+  const long need = (ntiles + 7) / 8;
+  if (slots > need) slots = need;
+  if (slots < 1) slots = 1;
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(w3_mlp_kernel<NS, DEPTH>), dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
+  const int rc = check_launch("w3_mlp_forward");
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+template <int NS> inline size_t w3_lds() { return (size_t)(NS > 1 ? 4 : 2) * W3_IMG; }   // two stages of hi (+ lo) images
+
+template <int NS>
+inline int w3_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
+  DPPM_TRY(ws_check(a, "w3_lin"));
+  if (a.side && (!a.wside || !ws_al16(a.side) || a.side_bs % 4)) return fail(DPPM_E_INVALID, "w3_lin: bad side input");
+  if (nsrc == 2)
+    for (int i = 0; i < a.njobs; ++i)
+      if (!a.job[i].X2 || !a.job[i].W2 || !ws_al16(a.job[i].X2) || a.job[i].x2_bs % 4) return fail(DPPM_E_INVALID, "w3_lin: job %d lacks its second source", i);
+  static bool set[4] = {false, false, false, false};
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  int rc;
+  if (nsrc == 1) rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 1, true>, w3_lds<NS>(), a, st, set[0], "w3_lin<1,T>")
+                            : ws_launch_kernel(w3_lin_kernel<NS, 1, false>, w3_lds<NS>(), a, st, set[1], "w3_lin<1,N>");
+  else rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 2, true>, w3_lds<NS>(), a, st, set[2], "w3_lin<2,T>")
+                  : ws_launch_kernel(w3_lin_kernel<NS, 2, false>, w3_lds<NS>(), a, st, set[3], "w3_lin<2,N>");
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  return rc;
+}
+
+}  // namespace dppm

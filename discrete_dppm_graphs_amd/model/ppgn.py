@@ -8,11 +8,17 @@ Drop-in contract
   * `get_out_dim()`, `train()/eval()`.
 Extensions: `noiselevel` may be a length-B sequence / tensor (one sigma per graph) so a whole training batch runs in
 one call, and `forward_backward` runs forward + loss gradient + backward without autograd (used by `fit`).
+`model.precision` ('f32' | 'bf16x3' | 'bf16'; config key `precision`, environment DPPM_PRECISION, default 'bf16x3')
+selects the matrix arithmetic of the H = 128 kernels for inference / sampling (include/dppm_hip.h DPPM_PREC_*;
+'bf16x3' holds the float32 parity bar, tests/test_gpu_ppgn.py).  Training forward + backward always run exact float32,
+and tensors stay float32 in every mode.
 
 Only the configuration that utils/loading_utils.py:98-119 builds is implemented in HIP (input_features=2, instance
 norm, cat_output, adj_out, layer_after_conv, no residual / project_first / node_out); anything else raises.
 All arithmetic happens in libdppm_hip.so; there is no PyTorch fallback.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -20,6 +26,16 @@ import torch.nn as nn
 from .. import ops
 
 SLOPE = 0.01
+
+
+def default_precision(config=None, key="precision", env="DPPM_PRECISION", fallback="bf16x3"):
+    """config.<key> if the YAML sets it, else $<env>, else `fallback`."""
+    p = None
+    if config is not None:
+        p = config.get(key) if isinstance(config, dict) else getattr(config, key, None)
+    p = p or os.environ.get(env) or fallback
+    ops._prec(p)   # validates
+    return p
 
 
 class _Seq(nn.Sequential):
@@ -62,7 +78,7 @@ class _PowerfulFn(torch.autograd.Function):
         pack = module._pack()
         B, N, _ = A.shape
         ws = module._workspace(B, N, training, A.device)
-        logits = ops.ppgn_forward(pack, A, mask, sigma, ws, training=training)
+        logits = ops.ppgn_forward(pack, A, mask, sigma, ws, training=training, precision=module.precision)
         if training:
             ctx.module, ctx.ws, ctx.pack = module, ws, pack
             ctx.save_for_backward(A, mask, sigma)
@@ -114,6 +130,7 @@ class Powerful(nn.Module):
         self.output_features = self.node_output_features = output_features
         self.noise_mlp = noise_mlp
         self.config = config
+        self.precision = default_precision(config)
         # same registration order as the reference so that seeded initialisation consumes the RNG identically
         self.time_mlp = nn.Sequential(nn.Linear(1, 4), nn.GELU(), nn.Linear(4, 1))
         self.in_lin = _Seq(nn.Linear(input_features, hidden))
@@ -161,7 +178,8 @@ class Powerful(nn.Module):
         """Inference forward returning logits [B, N, N] (no trailing singleton), reusing one cached workspace."""
         A, mask, sigma = self._prepare(A, mask, noiselevel)
         B, N, _ = A.shape
-        return ops.ppgn_forward(self._pack(), A, mask, sigma, self._workspace(B, N, False, A.device), training=False, out=out)
+        return ops.ppgn_forward(self._pack(), A, mask, sigma, self._workspace(B, N, False, A.device), training=False, out=out,
+                                precision=self.precision)
 
     # ------------------------------------------------------------------ helpers
     def used_param_names(self):

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import PpgnLayer, PpgnParams, check, lib
+from ._lib import PRECISIONS, PpgnLayer, PpgnParams, check, lib
 
 
 def _stream():
@@ -39,6 +39,14 @@ def _rng_args(U, seed, graph_id0, offset, shape):
 
 def _f32c(t):
     return t.to(torch.float32).contiguous()
+
+
+def _prec(precision):
+    """'f32' | 'bf16x3' | 'bf16' -> DPPM_PREC_* (include/dppm_hip.h)."""
+    try:
+        return PRECISIONS[precision]
+    except KeyError:
+        raise ValueError(f"precision {precision!r}: expected one of {sorted(PRECISIONS)}") from None
 
 
 def generate_mask(flags):
@@ -212,7 +220,7 @@ def ppgn_workspace(B, N, H, L, training, device):
     return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
 
 
-def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None):
+def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None, precision="f32"):
     A = _chk(A, "A")
     B, N, _ = A.shape
     mask = _chk(mask, "mask", (B, N, N))
@@ -221,7 +229,8 @@ def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None):
     logits = out if out is not None else torch.empty(B, N, N, device=A.device, dtype=torch.float32)
     _chk(logits, "out", (B, N, N))
     check(lib.dppm_ppgn_forward(pack.ref(), _ptr(A), _ptr(mask), _ptr(sigma), B, N, _ptr(logits), _ptr(workspace),
-                                C.c_size_t(workspace.numel() * 4), int(bool(training)), _stream()), "dppm_ppgn_forward")
+                                C.c_size_t(workspace.numel() * 4), int(bool(training)), _prec(precision), _stream()),
+          "dppm_ppgn_forward")
     return logits
 
 
@@ -263,7 +272,7 @@ def linear_fwd(W, X, bias=None, act=False, maskp=None, trans_w=False, out=None, 
     return Y
 
 
-def mlp_pair_fwd(X, weights, maskp=None, save_hidden=False):
+def mlp_pair_fwd(X, weights, maskp=None, save_hidden=False, precision="f32"):
     """X: [B, H, P]; weights: dict with the ten `m1.0.weight` ... `m4.0.bias`-style keys of one layer (m4 unused).
     -> (o1, o2, hid1 or None, hid2 or None)"""
     X = _chk(X, "X")
@@ -281,7 +290,7 @@ def mlp_pair_fwd(X, weights, maskp=None, save_hidden=False):
     h1 = torch.empty_like(X) if need_hid else None
     h2 = torch.empty_like(X) if need_hid else None
     check(lib.dppm_mlp_pair_fwd(_ptr(X), C.c_long(H * P), C.byref(layer), H, _ptr(maskp), _ptr(o1), _ptr(o2), _ptr(h1), _ptr(h2), B, P,
-                                _stream()), "dppm_mlp_pair_fwd")
+                                _prec(precision), _stream()), "dppm_mlp_pair_fwd")
     return o1, o2, h1, h2
 
 

@@ -35,6 +35,19 @@ extern "C" {
 #define DPPM_E_LAUNCH (-2)    /* HIP reported a launch / runtime error */
 #define DPPM_E_UNSUPPORTED (-3)
 
+/* Matrix arithmetic of the H = 128 per-position linears in INFERENCE forwards (operands and results are float32 in HBM
+ * in every mode; kernels that have no reduced form use DPPM_PREC_F32 silently; training forward + backward always run
+ * DPPM_PREC_F32: through the backward of the instance norms the 2^-16 products of the split form are amplified to
+ * ~50x the float32 gradient error, measured in tests/test_gpu_ppgn.py::test_backward_kinkfree_h128):
+ *   DPPM_PREC_F32     exact float32 products on v_mfma_f32_16x16x4_f32;
+ *   DPPM_PREC_BF16X3  each operand split into two bf16 pieces (hi + lo), a product = hi*hi + hi*lo + lo*hi on
+ *                     v_mfma_f32_16x16x32_bf16 with float32 accumulation: ~6e-6 of the result's magnitude per Linear,
+ *                     inside the 1e-3 float32 parity bar, at 3/16 of the f32 matrix time;
+ *   DPPM_PREC_BF16    operands rounded to bf16, float32 accumulation (~3e-3 per Linear; tolerance stated separately). */
+#define DPPM_PREC_F32 0
+#define DPPM_PREC_BF16X3 1
+#define DPPM_PREC_BF16 2
+
 const char* dppm_last_error(void);
 /* ABI version, bumped on any signature change. */
 int dppm_abi_version(void);
@@ -133,11 +146,12 @@ size_t dppm_ppgn_workspace_bytes(int B, int N, int H, int L, int training);
  * sigma: [B] floats on the device (the reference passes one python float per call; a vector lets a whole
  * training batch run in one call).  mask: [B][N][N], binary, node 0 of every graph active (the reference divides
  * by sqrt(sum_j mask[b][0][j]), model/ppgn.py:51).
+ * precision: DPPM_PREC_* (see above); ignored (exact float32) when training != 0.
  * Replaces model/ppgn.py:257-337 Powerful.forward/forward_cat, :47-71 PowerfulLayer.forward and
  * util/model_helper.py:176-191 masked_instance_norm2D. */
 int dppm_ppgn_forward(const dppm_ppgn_params* params_host, const float* A, const float* mask, const float* sigma,
                       int B, int N, float* logits, void* workspace, size_t workspace_bytes, int training,
-                      void* stream);
+                      int precision, void* stream);
 
 /* Gradients of sum(logits * dlogits) w.r.t. every parameter in *grads_host (same layout as params; every
  * buffer is overwritten).  `workspace` must be the one a dppm_ppgn_forward(training=1) call on the same inputs
@@ -174,9 +188,10 @@ int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float* X, long x
  *   o_k[b] = (W_k1 * LeakyReLU(W_k0 * X[b] + b_k0) + b_k1) * maskp[b],  k = 1, 2      (all matrices H x H, planes H x P).
  * hid1 / hid2 (nullable, both or none): the hidden activations, written only when a backward pass will need them.
  * H = 128 runs the weight-stationary fused kernel (hidden activations stay in LDS); other H use four GEMM launches and
- * then need hid1 / hid2 as scratch (not nullable). */
+ * then need hid1 / hid2 as scratch (not nullable).  precision != DPPM_PREC_F32 applies to H = 128 without saved hidden
+ * activations. */
 int dppm_mlp_pair_fwd(const float* X, long x_bs, const dppm_ppgn_layer* layer_host, int H, const float* maskp,
-                      float* o1, float* o2, float* hid1, float* hid2, int B, int P, void* stream);
+                      float* o1, float* o2, float* hid1, float* hid2, int B, int P, int precision, void* stream);
 
 /* dW (M x Nw, row pitch ldo) = sum_b dY[b] (M x P) * X[b]^T (P x Nw), db (nullable) [M] = sum_{b,p} dY[b][m][p]:
  * the weight/bias gradient of the Linear above (split-K partial slabs + ordered reduction, bitwise reproducible).

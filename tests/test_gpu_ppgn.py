@@ -41,14 +41,14 @@ def rand_case(rng, B, N, ragged=True):
     return A, mask
 
 
-def run_gpu(ops, W, A, mask, sigma, L, H, dlogits=None):
+def run_gpu(ops, W, A, mask, sigma, L, H, dlogits=None, precision="f32"):
     tensors = {k: dev(v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in W.items()}
     pack = ops.ParamPack(tensors, L, H)
     B, N, _ = A.shape
     ws = ops.ppgn_workspace(B, N, H, L, dlogits is not None, "cuda")
     ws.fill_(float("nan"))     # any read of an element no kernel wrote poisons the result
     sig = dev(np.broadcast_to(np.asarray(sigma, np.float64).astype(np.float32), (B,)).copy())
-    logits = ops.ppgn_forward(pack, dev(A), dev(mask), sig, ws, training=dlogits is not None)
+    logits = ops.ppgn_forward(pack, dev(A), dev(mask), sig, ws, training=dlogits is not None, precision=precision)
     grads = None
     if dlogits is not None:
         gt = {k: torch.full_like(v, float("nan")) for k, v in tensors.items()}
@@ -105,7 +105,9 @@ def test_backward_kinkfree_h128(ops, shift1, shift2, shift_ac):
     (B=4, N=96: 576 tiles of 64 positions).  The first-layer biases of the MLPs and of after_conv are shifted so that every
     LeakyReLU input is far from 0 (asserted on the oracle's side): the comparison is then free of kink flips and both
     derivative branches (1 and 0.01) are exercised.  Yardstick: the same graph evaluated in float64; the GPU result must
-    be about as close to it as torch's own float32 evaluation is (the shifted case amplifies rounding to ~1e-3)."""
+    be about as close to it as torch's own float32 evaluation is (the shifted case amplifies rounding to ~1e-3).
+    The inference forward in bf16x3 is checked on the same ill-conditioned network: its 2^-16 products are amplified by the
+    same factor (torch float32 itself is ~5e-5 off float64 here), so it gets 2e-3."""
     import torch.nn.functional as F
     from oracle import ppgn as op
     B, N, H, L = 4, 96, 128, 2
@@ -143,6 +145,8 @@ def test_backward_kinkfree_h128(ops, shift1, shift2, shift_ac):
     logits, grads = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
     lscale = np.abs(l64).max()
     assert np.abs(logits - l64).max() <= 4 * np.abs(l32 - l64).max() + 2e-5 * lscale
+    lx3, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    assert np.abs(lx3 - l64).max() <= 2e-3 * lscale
     gmax = max(np.abs(v).max() for v in g64.values())
     for n in g64:
         scale = max(np.abs(g64[n]).max(), 2e-2 * gmax)
@@ -237,6 +241,52 @@ def test_mlp_pair_block(ops, H, P, B, save):
         if save:
             close(h.cpu().numpy(), hid, tol=1e-5)
             assert ((h.cpu().numpy() > 0) != (pre > 0)).sum() <= 2      # sign flips only where the pre-activation is ~0
+
+
+# Reduced matrix arithmetic (include/dppm_hip.h DPPM_PREC_*).  bf16x3 (two-piece bf16 split, three MFMAs per product) is
+# held to the float32 parity bar of the north star (1e-3 relative; measured ~1e-5 per Linear, ~1e-4 end to end); plain bf16
+# is a separate, stated tolerance: 2e-2 of the tensor's magnitude per MLP, 1.5e-1 of max |logit| through L = 2..3 layers of a
+# random-initialised network (logits there are small differences of O(10) activations).
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("P,B", [(64, 1), (1188, 3), (40000, 1)])
+def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B):
+    H = 128
+    rng = np.random.default_rng(P)
+    X = rng.normal(size=(B, H, P)).astype(np.float32)
+    maskp = (rng.random((B, P)) < 0.8).astype(np.float32)
+    Wt = {}
+    for m in ("m1", "m2"):
+        for k in ("0", "2"):
+            Wt[f"{m}.{k}.weight"] = (rng.normal(size=(H, H)) / np.sqrt(H)).astype(np.float32)
+            Wt[f"{m}.{k}.bias"] = rng.normal(size=H).astype(np.float32)
+    o1, o2, _, _ = ops.mlp_pair_fwd(dev(X), {k: dev(v) for k, v in Wt.items()}, maskp=dev(maskp), precision=precision)
+    X64 = X.astype(np.float64)
+    for m, o in (("m1", o1), ("m2", o2)):
+        pre = np.einsum("ok,bkp->bop", Wt[f"{m}.0.weight"].astype(np.float64), X64) + Wt[f"{m}.0.bias"][None, :, None]
+        hid = np.where(pre > 0, pre, 0.01 * pre)
+        out = (np.einsum("ok,bkp->bop", Wt[f"{m}.2.weight"].astype(np.float64), hid) + Wt[f"{m}.2.bias"][None, :, None]) * maskp[:, None, :]
+        close(o.cpu().numpy(), out, tol=tol)
+
+
+@pytest.mark.parametrize("precision,ltol", [("bf16x3", 1e-3), ("bf16", 1.5e-1)])
+@pytest.mark.parametrize("B,N,L", [(2, 40, 3), (1, 200, 2), (2, 64, 8)])
+def test_forward_reduced_precision(ops, precision, ltol, B, N, L):
+    """Whole H = 128 network (inference forward) in the reduced modes against the oracle.  A training forward ignores the
+    mode (exact float32), which the last assertion checks bit for bit."""
+    from oracle import ppgn as op
+    H = 128
+    rng = np.random.default_rng(N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    inf, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    close(inf, ref, tol=ltol)
+    R = np.zeros_like(A)
+    t_mode, _ = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R, precision=precision)
+    t_f32, _ = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R, precision="f32")
+    assert np.array_equal(t_mode, t_f32)
 
 
 def test_inorm_vs_oracle(ops):
