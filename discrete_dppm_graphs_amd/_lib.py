@@ -58,7 +58,7 @@ SIGNATURES = {
     "dppm_ppgn_backward": (C.c_int, [C.POINTER(PpgnParams), C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                      c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "dppm_plane_matmul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
-                                    C.c_int, c_stream]),
+                                    C.c_int, C.c_int, c_stream]),
     "dppm_linear_fwd": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_long, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_long,
                                   C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "dppm_mlp_pair_fwd": (C.c_int, [c_f32p, C.c_long, C.POINTER(PpgnLayer), C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,

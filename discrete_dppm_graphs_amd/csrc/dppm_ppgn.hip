@@ -14,6 +14,7 @@
 #include "dppm_wsplit.h"
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
+#include "dppm_planesplit.h"
 #include <cstdlib>
 
 namespace dppm {
@@ -433,8 +434,12 @@ int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float*
 
 // per-plane products for all (b,c): C = op(A) * op(B) * inv_norm[b] (* mask[b])
 int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batch, int n, int ld, bool ta, bool tb,
-             const float* scale, const float* mask, int div) {
+             const float* scale, const float* mask, int div, int prec = DPPM_PREC_F32) {
   static const bool strip_off = getenv("DPPM_DISABLE_STRIPMM") != nullptr;   // A/B switch for measurements
+  if (prec != DPPM_PREC_F32 && !ta && !tb && plane3_supported(n) && aligned16(A) && aligned16(Bm) && aligned16(C)) {
+    PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // forward form on the bf16 pipe (dppm_planesplit.h)
+    return prec == DPPM_PREC_BF16X3 ? plane3_launch<3>(pa, batch, st) : plane3_launch<1>(pa, batch, st);
+  }
   if (plane_mm_supported(n) && !strip_off && aligned16(A) && aligned16(Bm) && aligned16(C)) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};
     return plane_mm_launch(pa, batch, /*a_kmajor=*/ta, /*b_kmajor=*/!tb, st);
@@ -481,12 +486,13 @@ extern "C" size_t dppm_ppgn_workspace_bytes(int B, int N, int H, int L, int trai
 }
 
 extern "C" int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int n, int ld, int trans_a, int trans_b,
-                                 const float* scale, const float* mask, int scale_div, void* stream) {
+                                 const float* scale, const float* mask, int scale_div, int precision, void* stream) {
   DPPM_REQUIRE(A && Bm && C, "dppm_plane_matmul: null pointer");
   DPPM_REQUIRE(batch > 0 && n > 0 && ld >= n && ld % 4 == 0, "dppm_plane_matmul: batch=%d n=%d ld=%d", batch, n, ld);
   DPPM_REQUIRE(!(trans_a && trans_b), "dppm_plane_matmul: A^T * B^T is not provided");
   DPPM_REQUIRE(scale_div >= 1, "dppm_plane_matmul: scale_div=%d", scale_div);
-  return plane_mm(as_stream(stream), A, Bm, C, batch, n, ld, trans_a != 0, trans_b != 0, scale, mask, scale_div);
+  DPPM_REQUIRE(valid_prec(precision), "dppm_plane_matmul: precision=%d", precision);
+  return plane_mm(as_stream(stream), A, Bm, C, batch, n, ld, trans_a != 0, trans_b != 0, scale, mask, scale_div, precision);
 }
 
 extern "C" int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float* X, long x_bs, int K, const float* bias, int act,
@@ -576,7 +582,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     float* y = c.at(w.tmp[3]);
     DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
-    DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H));
+    DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, prec));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
     if (use_wstat(H)) {
       WsArgs wa{};

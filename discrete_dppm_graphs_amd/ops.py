@@ -243,7 +243,7 @@ def ppgn_backward(pack, grad_pack, A, mask, sigma, dlogits, workspace):
           "dppm_ppgn_backward")
 
 
-def plane_matmul(A, Bm, n, trans_a=False, trans_b=False, scale=None, mask=None, scale_div=1):
+def plane_matmul(A, Bm, n, trans_a=False, trans_b=False, scale=None, mask=None, scale_div=1, precision="f32"):
     """A, Bm: [batch, n, ld] planes (ld = n rounded up to 4)."""
     A = _chk(A, "A")
     batch, n_, ld = A.shape
@@ -252,7 +252,7 @@ def plane_matmul(A, Bm, n, trans_a=False, trans_b=False, scale=None, mask=None, 
     Bm = _chk(Bm, "Bm", (batch, n, ld))
     out = torch.empty_like(A)
     check(lib.dppm_plane_matmul(_ptr(A), _ptr(Bm), _ptr(out), batch, n, ld, int(trans_a), int(trans_b), _ptr(scale), _ptr(mask),
-                                int(scale_div), _stream()), "dppm_plane_matmul")
+                                int(scale_div), _prec(precision), _stream()), "dppm_plane_matmul")
     return out
 
 

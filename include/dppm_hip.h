@@ -35,7 +35,7 @@ extern "C" {
 #define DPPM_E_LAUNCH (-2)    /* HIP reported a launch / runtime error */
 #define DPPM_E_UNSUPPORTED (-3)
 
-/* Matrix arithmetic of the H = 128 per-position linears in INFERENCE forwards (operands and results are float32 in HBM
+/* Matrix arithmetic of the H = 128 per-position linears and of the per-channel contraction in INFERENCE forwards (operands and results are float32 in HBM
  * in every mode; kernels that have no reduced form use DPPM_PREC_F32 silently; training forward + backward always run
  * DPPM_PREC_F32: through the backward of the instance norms the 2^-16 products of the split form are amplified to
  * ~50x the float32 gradient error, measured in tests/test_gpu_ppgn.py::test_backward_kinkfree_h128):
@@ -166,9 +166,9 @@ int dppm_ppgn_backward(const dppm_ppgn_params* params_host, const dppm_ppgn_para
 /* C[g] = epilogue(A[g] (MxK) * B[g] (KxN)) for g in [0,batch): the per-channel adjacency contraction
  * (model/ppgn.py:62 `out1 @ out2`), planes [N][ld].  trans_a / trans_b select A^T / B^T (backward).
  * scale (nullable): [batch / scale_div] multiplies the product; mask (nullable): [batch / scale_div][n][ld]
- * multiplies it elementwise. */
+ * multiplies it elementwise.  precision != DPPM_PREC_F32 applies to the forward form (no transposes) with 129 <= n <= 256. */
 int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int n, int ld, int trans_a, int trans_b,
-                      const float* scale, const float* mask, int scale_div, void* stream);
+                      const float* scale, const float* mask, int scale_div, int precision, void* stream);
 
 /* Masked instance norm over each [N][ld] plane (util/model_helper.py:176-191 + the `u * mask` of
  * model/ppgn.py:315).  y, u: [B][C][N*ld] with batch strides y_bs / u_bs (floats); maskp: [B][N*ld];

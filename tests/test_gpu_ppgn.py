@@ -195,6 +195,27 @@ def test_plane_matmul_variants(ops, n):
         assert np.all(out[:, :, n:] == 0)
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("n", [129, 144, 200, 203, 256])
+def test_plane_matmul_reduced_precision(ops, n, precision, tol):
+    """Forward contraction on the bf16 pipe (dppm_planesplit.h) incl. ragged sizes, with scale and mask, against float64."""
+    rng = np.random.default_rng(n)
+    ld = (n + 3) // 4 * 4
+    batch = 6
+    A = np.zeros((batch, n, ld), np.float32)
+    Bm = np.zeros((batch, n, ld), np.float32)
+    A[:, :, :n] = rng.normal(size=(batch, n, n))
+    Bm[:, :, :n] = rng.normal(size=(batch, n, n))
+    scale = rng.uniform(0.5, 2, size=3).astype(np.float32)
+    mask = np.zeros((3, n, ld), np.float32)
+    mask[:, :, :n] = rng.random((3, n, n)) < 0.8
+    ref = A[:, :, :n].astype(np.float64) @ Bm[:, :, :n].astype(np.float64)
+    ref = ref * np.repeat(scale, 2)[:, None, None] * np.repeat(mask[:, :, :n], 2, axis=0)
+    out = ops.plane_matmul(dev(A), dev(Bm), n, scale=dev(scale), mask=dev(mask), scale_div=2, precision=precision).cpu().numpy()
+    close(out[:, :, :n], ref, tol=tol)
+    assert np.all(out[:, :, n:] == 0)
+
+
 @pytest.mark.parametrize("M,K,P,B", [(8, 8, 48, 2), (34, 16, 1188, 3), (64, 64, 64, 2), (40, 64, 400, 1), (128, 128, 3600, 2),
                                      (194, 64, 64, 2), (66, 32, 400, 2), (32, 2, 400, 2), (130, 20, 132, 1)])
 def test_linear_fwd_and_wgrad_blocks(ops, M, K, P, B):
