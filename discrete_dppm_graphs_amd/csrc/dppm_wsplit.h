@@ -424,6 +424,125 @@ inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
   return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Two-source Linear  Y (+)= epilogue(W1 X1 + W2 X2 + b)  (the skip-concat m4 of model/ppgn.py:66-69, layer_cat_lin two
+// layer outputs at a time), split form.  Holding both matrices' hi and lo pieces (64 registers) next to the accumulators
+// and a prefetch set does not fit 128 registers, so the SOURCES go to different waves of one 16-wave workgroup per CU:
+// waves 0-7 hold W1 and stage / multiply X1, waves 8-15 hold W2 and stage / multiply X2; the second group hands its
+// partial tile to the first through LDS (lane-linear float4 rows: conflict-free both ways), which adds, applies the
+// epilogue and stores.  Per tile: MFMAs, barrier, [land tile t+1 (requested a whole tile earlier), request tile t+2,
+// epilogue of tile t], barrier.
+// ---------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int BUF = NIMG * W3_IMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 3, w8 = wave & 7;
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * w8 + ci;
+  char* Xs = smem3 + role * BUF;                                         // this group's source images
+  float4* Ps = reinterpret_cast<float4*>(smem3 + 2 * BUF) + (w8 * 4) * 64 + lane;   // partial tile: [w8][j][lane] float4
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+  if (who.rank >= ntiles) return;   // whole workgroup, before any barrier
+
+  uintx4 wh[4], wl[4];
+  w3_load_w<NS, false>(wh, wl, role ? J.W2 : J.W1, role ? J.ldw2 : J.ldw1, ch, g);
+  const float bv = J.b1 ? J.b1[ch] : 0.f;
+  const float* Xsrc = role ? J.X2 : J.X;
+  const long xbs = role ? J.x2_bs : J.x_bs;
+
+  const int u = tid & 511;
+  const unsigned o0 = (unsigned)(4 * (u >> 4)) * P + 4 * (u & 15);
+  const int oc = 4 * (u & 15);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+  const W3Addr ad = w3_addr(ci, g);
+  const int nloc = (ntiles - who.rank + who.per_job - 1) / who.per_job;
+
+  W3Pre pre;
+  auto issue = [&](int i) {   // unconditional, clamped (see w3_mlp_kernel)
+    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const float* Xt = Xsrc + (size_t)b * xbs + p0 + ((p0 + oc < P) ? o0 : 0u);
+    pre.a = *reinterpret_cast<const float4*>(Xt);
+    pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+    pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+    pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+  };
+  auto land = [&](int i) {
+    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    const bool in = p0 + oc < P;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs, u);
+  };
+  issue(0);
+  land(0);
+  issue(1);
+  __syncthreads();
+  for (int i = 0; i < nloc; ++i) {
+    const int t = who.rank + i * who.per_job;
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    w3_mma4<NS, false>(acc, wh, wl, Xs, ad);
+    if (role == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ps[j * 64] = ws_f4(acc[j]);
+    }
+    __syncthreads();
+    land(i + 1);          // requested one tile ago
+    issue(i + 2);
+    if (role == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 q = Ps[j * 64];
+        acc[j][0] += q.x; acc[j][1] += q.y; acc[j][2] += q.z; acc[j][3] += q.w;
+      }
+      if (a.side) {   // uniform branch
+        const float s0 = a.wside[(size_t)ch * a.ldws], s1 = a.wside[(size_t)ch * a.ldws + 1];
+        const float* St = a.side + (size_t)b * a.side_bs + p0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((int)m0 + 16 * j < P - p0) {
+            const float4 x0 = *reinterpret_cast<const float4*>(St + m0 + 16 * j);
+            const float4 x1 = *reinterpret_cast<const float4*>(St + P + m0 + 16 * j);
+            acc[j][0] += s0 * x0.x + s1 * x1.x; acc[j][1] += s0 * x0.y + s1 * x1.y;
+            acc[j][2] += s0 * x0.z + s1 * x1.z; acc[j][3] += s0 * x0.w + s1 * x1.w;
+          }
+        }
+      }
+      ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
+                   J.accumulate != 0);
+    }
+    __syncthreads();
+  }
+}
+
+template <int NS>
+inline int w3_lin2(const WsArgs& a, hipStream_t st) {
+  static bool set = false;
+  const size_t lds = (size_t)(NS > 1 ? 4 : 2) * W3_IMG + (size_t)WS_H * WS_TP * sizeof(float);
+  if (!set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(w3_lin2_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "w3_lin2: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    set = true;
+  }
+  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
+  long slots = 32 / a.njobs;                       // one workgroup per CU: 32 per XCD
+  const long need = (ntiles + 7) / 8;
+  if (slots > need) slots = need;
+  if (slots < 1) slots = 1;
+  hipLaunchKernelGGL(w3_lin2_kernel<NS>, dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
+  return check_launch("w3_lin2");
+}
+
 template <int NS> inline size_t w3_lds() { return (size_t)(NS > 1 ? 4 : 2) * W3_IMG; }   // two stages of hi (+ lo) images
 
 template <int NS>
@@ -439,6 +558,7 @@ inline int w3_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   int rc;
   if (nsrc == 1) rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 1, true>, w3_lds<NS>(), a, st, set[0], "w3_lin<1,T>")
                             : ws_launch_kernel(w3_lin_kernel<NS, 1, false>, w3_lds<NS>(), a, st, set[1], "w3_lin<1,N>");
+  else if (!trans && NS > 1) rc = w3_lin2<NS>(a, st);   // the split form of two matrices does not fit one wave's registers
   else rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 2, true>, w3_lds<NS>(), a, st, set[2], "w3_lin<2,T>")
                   : ws_launch_kernel(w3_lin_kernel<NS, 2, false>, w3_lds<NS>(), a, st, set[3], "w3_lin<2,N>");
   if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs);

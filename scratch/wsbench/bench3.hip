@@ -79,6 +79,13 @@ int main(int argc, char** argv) {
   add("f32 lin<2>", 2 * unit, 3 * SB, [&] { return ws_lin(l, 2, false, 0); });
   add("bf16x3 lin<2>", 2 * unit, 3 * SB, [&] { return w3_lin<3>(l3, 2, false, 0); });
   cmp("lin<2> x3", Y0, Z0, S);
+  { WsArgs la = l3; la.job[0].accumulate = 1; la.side = X2; la.side_bs = hs; la.wside = W[5]; la.ldws = 2 * H; la.maskp = mask;
+    WsArgs lb = l; lb.job[0].accumulate = 1; lb.side = X2; lb.side_bs = hs; lb.wside = W[5]; lb.ldws = 2 * H; lb.maskp = mask;
+    hipMemset(Y0, 0, S * 4); hipMemset(Z0, 0, S * 4);
+    ws_lin(lb, 2, false, 0); w3_lin<3>(la, 2, false, 0); hipDeviceSynchronize();
+    cmp("lin<2> x3 acc+side+mask", Y0, Z0, S);
+    add("f32 lin<2> acc side", 2 * unit, 4 * SB, [=] { return ws_lin(lb, 2, false, 0); });
+    add("bf16x3 lin<2> acc side", 2 * unit, 4 * SB, [=] { return w3_lin<3>(la, 2, false, 0); }); }
   add("bf16 lin<2>", 2 * unit, 3 * SB, [&] { return w3_lin<1>(l3, 2, false, 0); });
   cmp("lin<2> bf16", Y0, Z0, S);
 
