@@ -7,7 +7,9 @@ Workload (BASELINE.json configs[3], the configuration the metric is quoted on): 
 the 8 x 128 PPGN of gridsearch_ppgn_simple.py:19, `ppgn_simple` sampling with 64 noise levels, 32 graphs per GPU.
 One step = one full reverse chain (x_T init, then 64 x [re-noise, denoiser forward, reverse step]) over one batch; graphs
 are independent, so ranks take disjoint graph ids and exchange nothing (weak scaling).  `value` = graphs finished per
-second over all ranks.  The same line also carries the training throughput (optimizer steps/s at global batch
+second over all ranks.  The sampler's denoiser runs in `--precision` (default bf16x3: float32 tensors, H=128 matrix
+products as three bf16 MFMAs on split operands with float32 accumulation, held to the float32 parity bar by
+tests/test_gpu_ppgn.py); `exact_f32` carries the same chain with exact-float32 MFMAs for comparison.  The same line also carries the training throughput (optimizer steps/s at global batch
 32 x N GPUs, data parallel with one flat-gradient all-reduce per step), the roofline of the dominant kernel measured
 live with HIP events, and a CPU baseline (the oracle's torch-CPU restatement on the host cores, bounded sample).
 """
@@ -25,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # idem, dense bf16
 HBM_PEAK_GBS = 8000.0
 
 
@@ -84,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="graphs per GPU")
     ap.add_argument("--train-steps", type=int, default=3, help="timed optimizer steps for the training figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-float32 comparison chain")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the sampler's H=128 kernels (include/dppm_hip.h DPPM_PREC_*)")
     args = ap.parse_args()
@@ -135,6 +139,20 @@ def main():
     assert out.shape == (B, N, N) and torch.equal(out, out.transpose(1, 2))
     graphs_per_s = args.steps * B * world / dt
 
+    # the same chain with exact-float32 matrix products (one warm-up chain, one timed), rank 0's clock
+    exact = None
+    if args.precision != "f32" and not args.no_exact_f32:
+        model.precision = "f32"
+        engine.sample_chain_simple(model, flags, T, seed, gid0)
+        barrier()
+        t0 = time.perf_counter()
+        engine.sample_chain_simple(model, flags, T, seed + 100, gid0)
+        barrier()
+        edt = time.perf_counter() - t0
+        exact = {"value": B * world / edt, "unit": "graphs/s", "ms_per_step": 1e3 * edt, "steps": 1,
+                 "note": "same workload with DPPM_PREC_F32 (v_mfma_f32_16x16x4_f32) in every kernel"}
+        model.precision = args.precision
+
     # ------------------------------------------------------------------ training throughput (second half of the metric)
     train = None
     if args.train_steps > 0:
@@ -172,9 +190,14 @@ def main():
         # dominant kernel: the fused MLP pair when H = 128 (weight-stationary path), else the generic linear GEMM
         dom_key = "wstat_mlp2" if prof["wstat_mlp2"]["launches"] > 0 else "linear_gemm"
         dom = prof[dom_key]
+        split = args.precision != "f32" and dom_key == "wstat_mlp2"
         dom_name = {"wstat_mlp2": "ws_mlp_kernel<false,false,false> (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32; "
                                   "8*H^2*P*B FLOP per launch)",
                     "linear_gemm": "gemm_f32_kernel<...,TAG=0> (per-position linear layers, v_mfma_f32_32x32x2_f32)"}[dom_key]
+        if split:
+            dom_name = ("w3_mlp_kernel<%d,%d> (both per-position MLPs of a PPGN layer; float32 in HBM, operands split into bf16 pieces in "
+                        "LDS, v_mfma_f32_16x16x32_bf16; algorithmic traffic 3*B*H*P*4 bytes per launch: read X, write o1 and o2)"
+                        % ((3, 1) if args.precision == "bf16x3" else (1, 2)))
         F = fwd_flops_per_graph(N, H, L)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_aggregate.py from rocprofv3 --pmc passes
@@ -182,27 +205,49 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("geometry") == {"nodes": N, "hidden": H, "layers": L, "graphs_per_gpu": B}:
                 traffic = tj.get("bytes_per_launch", {}).get(dom_key)
+        avg_ms = dom["ms"] / max(dom["launches"], 1)
+        common = {"traffic": traffic, "launches": dom["launches"], "avg_launch_ms": avg_ms,
+                  "flops_per_launch": dom["work"] / max(dom["launches"], 1), "share_of_step_time": dom["ms"] * 1e-3 / dt,
+                  "records_truncated": truncated}
+        if split:     # HBM-bound: 3 plane sets of B*H*P floats per launch (P = N * round_up(N, 4))
+            alg_bytes = 3.0 * B * H * N * ((N + 3) // 4 * 4) * 4
+            gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            nterm = 3 if args.precision == "bf16x3" else 1
+            roofline = {"kernel": dom_name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "bytes_per_launch": alg_bytes, "f32_equivalent_tflops": tf(dom),
+                        "bf16_mfma_frac": nterm * tf(dom) / BF16_MFMA_PEAK_TFLOPS, **common}
+        else:
+            roofline = {"kernel": dom_name, "bound": "mfma", "achieved": tf(dom), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf(dom) / F32_MFMA_PEAK_TFLOPS, **common}
+        mm_hbm = None
+        if split and pmm["ms"] > 0:
+            mm_bytes = 3.0 * B * H * N * ((N + 3) // 4 * 4) * 4 * pmm["launches"]
+            mm_hbm = {"achieved": mm_bytes / (pmm["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": mm_bytes / (pmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         line = {
             "metric": "graphs sampled/s (PPGN, N=200); train steps/s in `train`", "value": graphs_per_s, "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "f32 (tensors float32; H=128 products on bf16x3-split MFMA, float32 accumulate, 1e-3 parity bar held)",
+                      "bf16": "bf16 products, float32 tensors and accumulation"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": f"ppgn_simple sampling on synthetic SBM N={N} (BASELINE configs[3]): {L}x{H} PPGN, "
                                    f"{T} noise levels, {B} graphs/GPU per chain", "nodes": N, "hidden": H, "layers": L,
                        "noise_levels": T, "graphs_per_gpu": B, "parallelism": f"graph-sharded x{world}, no collective"},
             "model_tflops": graphs_per_s * T * F / 1e12,
-            "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": tf(dom), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf(dom) / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                         "flops_per_launch": dom["work"] / max(dom["launches"], 1),
-                         "share_of_step_time": dom["ms"] * 1e-3 / dt, "records_truncated": truncated},
-            "roofline_linear_all": {"kernel": "every per-position linear layer (ws_mlp_kernel, ws_lin_kernel<2>, ws_lin_kernel<1>; generic GEMM when H != 128)",
-                                    "bound": "mfma", "achieved": tf(lin), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": roofline,
+            "roofline_linear_all": {"kernel": "every per-position linear layer (w3_mlp_kernel, w3_lin2_kernel, w3_lin_kernel in the split modes; "
+                                              "ws_mlp_kernel, ws_lin_kernel<2>, ws_lin_kernel<1> in f32; generic GEMM when H != 128)",
+                                    "bound": "hbm (f32-equivalent TFLOP/s shown against the f32 MFMA peak it would need)" if split else "mfma",
+                                    "achieved": tf(lin), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf(lin) / F32_MFMA_PEAK_TFLOPS, "share_of_step_time": lin["ms"] * 1e-3 / dt,
                                     "by_kernel": {k: {"tflops": tf(prof[k]), "launches": prof[k]["launches"],
                                                       "avg_launch_ms": prof[k]["ms"] / max(prof[k]["launches"], 1)} for k in lin_keys}},
-            "roofline_matmul": {"kernel": "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)",
+            "roofline_matmul": {"kernel": ("plane3_kernel (per-channel N x N contraction, split-bf16 operands on v_mfma_f32_16x16x32_bf16, model/ppgn.py:62)"
+                                           if split else
+                                           "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)"),
                                 "bound": "mfma", "achieved": tf(pmm), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tf(pmm) / F32_MFMA_PEAK_TFLOPS,
+                                "frac": tf(pmm) / F32_MFMA_PEAK_TFLOPS, "hbm": mm_hbm,
                                 "launches": pmm["launches"], "avg_launch_ms": pmm["ms"] / max(pmm["launches"], 1),
                                 "share_of_step_time": pmm["ms"] * 1e-3 / dt},
             "roofline_inorm": {"bound": "hbm", "achieved": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9) if nrm["ms"] > 0 else 0.0,
@@ -210,6 +255,7 @@ def main():
                                "frac": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if nrm["ms"] > 0 else 0.0,
                                "avg_launch_ms": nrm["ms"] / max(nrm["launches"], 1),
                                "share_of_step_time": nrm["ms"] * 1e-3 / dt},
+            "exact_f32": exact,
             "train": train,
         }
         if not args.no_cpu_baseline:

@@ -119,11 +119,9 @@ __device__ __forceinline__ void p3_body(const PlaneArgs& p, char* lds, int g, in
   __syncthreads();
   const int ci = lane & 15, gq = lane >> 4;
   int stage = 0;
-  for (int k0 = 0; k0 < n; k0 += P3_BK) {
-    const int kn = k0 + P3_BK < n ? k0 + P3_BK : 0;     // past the end: re-read panel 0 (never consumed)
-    issue(kn, pre);
+  auto mma = [&](int st) {
     if (NR > 0 && NC > 0) {
-      const char* ai = lds + stage * STAGE;
+      const char* ai = lds + st * STAGE;
       const char* bi = ai + OPB;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
@@ -144,10 +142,16 @@ __device__ __forceinline__ void p3_body(const PlaneArgs& p, char* lds, int g, in
         }
       }
     }
-    land(kn, pre, lds + (stage ^ 1) * STAGE);
+  };
+  int k0 = 0;
+  for (; k0 + P3_BK < n; k0 += P3_BK) {   // every panel but the last: request the next one, multiply, land it
+    issue(k0 + P3_BK, pre);
+    mma(stage);
+    land(k0 + P3_BK, pre, lds + (stage ^ 1) * STAGE);
     __syncthreads();
     stage ^= 1;
   }
+  mma(stage);                             // last panel: nothing left to request (no wasted re-read)
   const float scale = p.scale ? p.scale[g / p.div] : 1.f;
   const float* mask = p.mask ? p.mask + (size_t)(g / p.div) * plane : nullptr;
   float* C = p.C + g * plane;

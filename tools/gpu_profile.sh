@@ -12,10 +12,10 @@ timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
     python3 "$REPO/bench.py" --steps 1 --warmup 1 --train-steps 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.err"; exit 1; }
 echo "kernel-trace pass done"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- \
-    python3 "$REPO/bench.py" --steps 1 --warmup 0 --levels 2 --train-steps 0 --no-cpu-baseline > "$OUT/fetch.out" 2> "$OUT/fetch.err" || { echo "fetch pass failed"; tail -5 "$OUT/fetch.err"; exit 1; }
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --levels 2 --train-steps 0 --no-cpu-baseline --no-exact-f32 > "$OUT/fetch.out" 2> "$OUT/fetch.err" || { echo "fetch pass failed"; tail -5 "$OUT/fetch.err"; exit 1; }
 echo "fetch pass done"
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- \
-    python3 "$REPO/bench.py" --steps 1 --warmup 0 --levels 2 --train-steps 0 --no-cpu-baseline > "$OUT/write.out" 2> "$OUT/write.err" || { echo "write pass failed"; tail -5 "$OUT/write.err"; exit 1; }
+    python3 "$REPO/bench.py" --steps 1 --warmup 0 --levels 2 --train-steps 0 --no-cpu-baseline --no-exact-f32 > "$OUT/write.out" 2> "$OUT/write.err" || { echo "write pass failed"; tail -5 "$OUT/write.err"; exit 1; }
 echo "write pass done"
 cd "$REPO"
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -n 1)

@@ -11,8 +11,10 @@ import json
 import sys
 from collections import defaultdict
 
-CLASS_OF = (("ws_mlp_kernel", "wstat_mlp2"), ("ws_lin_kernel<2", "wstat_sum2"), ("ws_lin_kernel<1", "wstat_cols"),
-            ("plane_mm", "plane_matmul"), ("inorm_fwd", "inorm"), ("gemm_f32_kernel", "linear_gemm"))
+CLASS_OF = (("ws_mlp_kernel", "wstat_mlp2"), ("w3_mlp_kernel", "wstat_mlp2"), ("ws_lin_kernel<2", "wstat_sum2"), ("w3_lin2_kernel", "wstat_sum2"),
+            ("w3_lin_kernel<3, 2", "wstat_sum2"), ("w3_lin_kernel<1, 2", "wstat_sum2"), ("ws_lin_kernel<1", "wstat_cols"),
+            ("w3_lin_kernel<3, 1", "wstat_cols"), ("w3_lin_kernel<1, 1", "wstat_cols"),
+            ("plane_mm", "plane_matmul"), ("plane3_kernel", "plane_matmul"), ("inorm_fwd", "inorm"), ("gemm_f32_kernel", "linear_gemm"))
 
 
 def per_kernel(path, counter):
@@ -38,8 +40,8 @@ def main():
         kernels[name] = {"launches": max(nf, nw), "FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w,
                          "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
     by_class = {}
-    for pat, cls in CLASS_OF:
-        sel = [(k, v) for k, v in kernels.items() if pat in k]
+    for cls in dict.fromkeys(c for _, c in CLASS_OF):
+        sel = [(k, v) for k, v in kernels.items() if any(pat in k for pat, c in CLASS_OF if c == cls)]
         if not sel:
             continue
         n = sum(v["launches"] for _, v in sel)
