@@ -166,7 +166,7 @@ int dppm_ppgn_backward(const dppm_ppgn_params* params_host, const dppm_ppgn_para
 /* C[g] = epilogue(A[g] (MxK) * B[g] (KxN)) for g in [0,batch): the per-channel adjacency contraction
  * (model/ppgn.py:62 `out1 @ out2`), planes [N][ld].  trans_a / trans_b select A^T / B^T (backward).
  * scale (nullable): [batch / scale_div] multiplies the product; mask (nullable): [batch / scale_div][n][ld]
- * multiplies it elementwise.  precision != DPPM_PREC_F32 applies to the forward form (no transposes) with 129 <= n <= 256. */
+ * multiplies it elementwise.  precision != DPPM_PREC_F32 applies to the forward form (no transposes) with 129 <= n <= 1024. */
 int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int n, int ld, int trans_a, int trans_b,
                       const float* scale, const float* mask, int scale_div, int precision, void* stream);
 

@@ -154,16 +154,18 @@ def test_backward_kinkfree_h128(ops, shift1, shift2, shift_ac):
         assert err_gpu <= 4 * err_f32 + 2e-4 * scale, f"{n}: gpu {err_gpu:.3e} vs torch-f32 {err_f32:.3e} (scale {scale:.3e})"
 
 
-def test_forward_n512_h128(ops):
-    """BASELINE configs[4] geometry (N=512, H=128), one graph and one layer: logits against the oracle."""
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16x3", 1e-3), ("bf16", 1.5e-1)])
+def test_forward_n512_h128(ops, precision, tol):
+    """BASELINE configs[4] geometry (N=512, H=128), one graph and one layer: logits against the oracle in every precision
+    (the bf16 tolerance is the separately stated one)."""
     from oracle import ppgn as op
     rng = np.random.default_rng(512)
     A, mask = rand_case(rng, 1, 512)
     W = op.init_weights(1, 128, seed=3)
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, 0.3, 1).squeeze(-1).numpy()
-    logits, _ = run_gpu(ops, W, A, mask, 0.3, 1, 128)
-    close(logits, ref)
+    logits, _ = run_gpu(ops, W, A, mask, 0.3, 1, 128, precision=precision)
+    close(logits, ref, tol=tol)
 
 
 def test_inference_equals_training_forward(ops):
@@ -196,7 +198,7 @@ def test_plane_matmul_variants(ops, n):
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("n", [129, 144, 200, 203, 256])
+@pytest.mark.parametrize("n", [129, 144, 200, 203, 256, 257, 300, 512])
 def test_plane_matmul_reduced_precision(ops, n, precision, tol):
     """Forward contraction on the bf16 pipe (dppm_planesplit.h) incl. ragged sizes, with scale and mask, against float64."""
     rng = np.random.default_rng(n)
