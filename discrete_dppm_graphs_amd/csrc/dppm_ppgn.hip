@@ -129,16 +129,17 @@ __device__ __forceinline__ float block_sum_1024(float v, float* sh) {   // all t
   return t;
 }
 
-constexpr int NORM_THREADS = 1024;
+constexpr int NORM_THREADS = 1024;   // large planes; small ones use 256 or 64 threads (norm_threads below)
 constexpr int NORM_CACHE = 10;   // float4 per thread kept in registers: planes up to 40960 floats stay on chip
 
 // masked instance norm, one workgroup per (b,c) plane: mean, then variance around it, then normalise
 // (two-pass statistics as in util/model_helper.py:182-189; the plane is read from HBM once and kept in registers)
-__global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __restrict__ y, long y_bs,
+template <int NTH>
+__global__ __launch_bounds__(NTH) void inorm_fwd_kernel(const float* __restrict__ y, long y_bs,
                                                                  const float* __restrict__ maskp, float* __restrict__ u,
                                                                  long u_bs, int C, int P, float* __restrict__ mean_out,
                                                                  float* __restrict__ rstd_out) {
-  __shared__ float sh[NORM_THREADS / 64];
+  __shared__ float sh[NTH / 64];
   const int b = blockIdx.x / C, c = blockIdx.x % C;
   const float4* yp = reinterpret_cast<const float4*>(y + (size_t)b * y_bs + (size_t)c * P);
   const float4* mp = reinterpret_cast<const float4*>(maskp + (size_t)b * P);
@@ -148,14 +149,14 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __
   float s = 0.f, cnt = 0.f;
 #pragma unroll
   for (int v = 0; v < NORM_CACHE; ++v) {
-    const int idx = threadIdx.x + v * NORM_THREADS;
+    const int idx = threadIdx.x + v * NTH;
     cy[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     cm[v] = cy[v];
     if (idx < P4) { cy[v] = yp[idx]; cm[v] = mp[idx]; }
     s += cy[v].x * cm[v].x + cy[v].y * cm[v].y + cy[v].z * cm[v].z + cy[v].w * cm[v].w;
     cnt += cm[v].x + cm[v].y + cm[v].z + cm[v].w;
   }
-  for (int idx = threadIdx.x + NORM_CACHE * NORM_THREADS; idx < P4; idx += NORM_THREADS) {
+  for (int idx = threadIdx.x + NORM_CACHE * NTH; idx < P4; idx += NTH) {
     const float4 a = yp[idx], m = mp[idx];
     s += a.x * m.x + a.y * m.y + a.z * m.z + a.w * m.w;
     cnt += m.x + m.y + m.z + m.w;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __
     const float dz = (cy[v].z - mean) * cm[v].z, dw = (cy[v].w - mean) * cm[v].w;
     q += dx * dx + dy * dy + dz * dz + dw * dw;
   }
-  for (int idx = threadIdx.x + NORM_CACHE * NORM_THREADS; idx < P4; idx += NORM_THREADS) {
+  for (int idx = threadIdx.x + NORM_CACHE * NTH; idx < P4; idx += NTH) {
     const float4 a = yp[idx], m = mp[idx];
     const float dx = (a.x - mean) * m.x, dy = (a.y - mean) * m.y, dz = (a.z - mean) * m.z, dw = (a.w - mean) * m.w;
     q += dx * dx + dy * dy + dz * dz + dw * dw;
@@ -179,12 +180,12 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __
   const float rstd = 1.f / sqrtf(q / cnt + 1e-5f);
 #pragma unroll
   for (int v = 0; v < NORM_CACHE; ++v) {
-    const int idx = threadIdx.x + v * NORM_THREADS;
+    const int idx = threadIdx.x + v * NTH;
     if (idx < P4)
       up[idx] = make_float4((cy[v].x - mean) * rstd * cm[v].x, (cy[v].y - mean) * rstd * cm[v].y,
                             (cy[v].z - mean) * rstd * cm[v].z, (cy[v].w - mean) * rstd * cm[v].w);
   }
-  for (int idx = threadIdx.x + NORM_CACHE * NORM_THREADS; idx < P4; idx += NORM_THREADS) {
+  for (int idx = threadIdx.x + NORM_CACHE * NTH; idx < P4; idx += NTH) {
     const float4 a = yp[idx], m = mp[idx];
     up[idx] = make_float4((a.x - mean) * rstd * m.x, (a.y - mean) * rstd * m.y, (a.z - mean) * rstd * m.z,
                           (a.w - mean) * rstd * m.w);
@@ -198,12 +199,13 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_fwd_kernel(const float* __
 // dy = rstd * m * (g - mean_m(g) - (u - mean_m(u)) * mean_m(g*u))   (u already carries the mask).
 // mean_m(u) is zero in exact arithmetic; keeping it makes sum(dy) vanish structurally, as it does in the autograd
 // graph of util/model_helper.py:182-190 (the rounding of the forward mean otherwise leaks a constant into dy).
-__global__ __launch_bounds__(NORM_THREADS) void inorm_bwd_kernel(const float* __restrict__ g, long g_bs,
+template <int NTH>
+__global__ __launch_bounds__(NTH) void inorm_bwd_kernel(const float* __restrict__ g, long g_bs,
                                                                  const float* __restrict__ u, long u_bs,
                                                                  const float* __restrict__ maskp,
                                                                  const float* __restrict__ rstd_in, float* __restrict__ dy,
                                                                  int C, int P) {
-  __shared__ float sh[NORM_THREADS / 64];
+  __shared__ float sh[NTH / 64];
   const int b = blockIdx.x / C, c = blockIdx.x % C;
   const float4* gp = reinterpret_cast<const float4*>(g + (size_t)b * g_bs + (size_t)c * P);
   const float4* up = reinterpret_cast<const float4*>(u + (size_t)b * u_bs + (size_t)c * P);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_bwd_kernel(const float* __
   float4* dp = reinterpret_cast<float4*>(dy + ((size_t)b * C + c) * P);
   const int P4 = P / 4;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f, cnt = 0.f;
-  for (int idx = threadIdx.x; idx < P4; idx += NORM_THREADS) {
+  for (int idx = threadIdx.x; idx < P4; idx += NTH) {
     const float4 a = gp[idx], x = up[idx], m = mp[idx];
     s1 += a.x * m.x + a.y * m.y + a.z * m.z + a.w * m.w;
     s2 += a.x * x.x + a.y * x.y + a.z * x.z + a.w * x.w;
@@ -224,11 +226,30 @@ __global__ __launch_bounds__(NORM_THREADS) void inorm_bwd_kernel(const float* __
   cnt = block_sum_1024(cnt, sh);
   const float rstd = rstd_in[blockIdx.x];
   const float m1 = s1 / cnt, m2 = s2 / cnt, ubar = s3 / cnt;
-  for (int idx = threadIdx.x; idx < P4; idx += NORM_THREADS) {
+  for (int idx = threadIdx.x; idx < P4; idx += NTH) {
     const float4 a = gp[idx], x = up[idx], m = mp[idx];
     dp[idx] = make_float4(rstd * m.x * (a.x - m1 - (x.x - ubar) * m2), rstd * m.y * (a.y - m1 - (x.y - ubar) * m2),
                           rstd * m.z * (a.z - m1 - (x.z - ubar) * m2), rstd * m.w * (a.w - m1 - (x.w - ubar) * m2));
   }
+}
+
+// workgroup size for planes of P floats: one float4 per thread and pass up to NORM_CACHE passes stay in registers; a 1024-thread
+// group on a 360-float plane (N = 18) spends its time in the three block reductions (22 us per launch, measured)
+inline int norm_threads(int P) { return P <= 512 ? 64 : (P <= 4096 ? 256 : NORM_THREADS); }
+
+template <typename... Args>
+inline void launch_inorm_fwd(int P, int nplanes, hipStream_t st, Args... args) {
+  const int nth = norm_threads(P);
+  if (nth == 64) hipLaunchKernelGGL(inorm_fwd_kernel<64>, dim3(nplanes), dim3(64), 0, st, args...);
+  else if (nth == 256) hipLaunchKernelGGL(inorm_fwd_kernel<256>, dim3(nplanes), dim3(256), 0, st, args...);
+  else hipLaunchKernelGGL(inorm_fwd_kernel<NORM_THREADS>, dim3(nplanes), dim3(NORM_THREADS), 0, st, args...);
+}
+template <typename... Args>
+inline void launch_inorm_bwd(int P, int nplanes, hipStream_t st, Args... args) {
+  const int nth = norm_threads(P);
+  if (nth == 64) hipLaunchKernelGGL(inorm_bwd_kernel<64>, dim3(nplanes), dim3(64), 0, st, args...);
+  else if (nth == 256) hipLaunchKernelGGL(inorm_bwd_kernel<256>, dim3(nplanes), dim3(256), 0, st, args...);
+  else hipLaunchKernelGGL(inorm_bwd_kernel<NORM_THREADS>, dim3(nplanes), dim3(NORM_THREADS), 0, st, args...);
 }
 
 // logits[b][i][j] = sum_o wfin[o] * (R + act)[b][o][p] + bfin     (model/ppgn.py:331-333; dropout is identity in eval)
@@ -538,8 +559,7 @@ extern "C" int dppm_inorm_fwd(const float* y, long y_bs, const float* maskp, flo
   DPPM_REQUIRE(y && maskp && u, "dppm_inorm_fwd: null pointer");
   DPPM_REQUIRE(B > 0 && C > 0 && P > 0 && P % 4 == 0 && y_bs % 4 == 0 && u_bs % 4 == 0, "dppm_inorm_fwd: B=%d C=%d P=%d", B, C, P);
   DPPM_REQUIRE(aligned16(y) && aligned16(maskp) && aligned16(u), "dppm_inorm_fwd: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(inorm_fwd_kernel, dim3(B * C), dim3(NORM_THREADS), 0, as_stream(stream), y, y_bs, maskp, u, u_bs, C, P,
-                     mean_out, rstd_out);
+  launch_inorm_fwd(P, B * C, as_stream(stream), y, y_bs, maskp, u, u_bs, C, P, mean_out, rstd_out);
   return check_launch("dppm_inorm_fwd");
 }
 
@@ -597,8 +617,8 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     }
     // masked instance norm, * mask; result lands in its slot of CAT   (model/ppgn.py:307,315-316)
     if (prof_enabled()) prof_before(c.st);
-    hipLaunchKernelGGL(inorm_fwd_kernel, dim3(B * H), dim3(NORM_THREADS), 0, c.st, y, hs, maskp, cat + (size_t)(2 + l * H) * P,
-                       cat_bs, H, P, (float*)nullptr, c.at(w.rstd) + (size_t)l * B * H);
+    launch_inorm_fwd(P, B * H, c.st, (const float*)y, hs, (const float*)maskp, cat + (size_t)(2 + l * H) * P, cat_bs, H, P, (float*)nullptr,
+                     c.at(w.rstd) + (size_t)l * B * H);
     if (prof_enabled()) prof_after(c.st, PROF_NORM, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
     DPPM_TRY(check_launch("inorm_fwd"));
   }
@@ -720,8 +740,8 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     const float* o2 = c.at(w.o2) + (size_t)l * w.S;
     const float* mm = c.at(w.mm) + (size_t)l * w.S;
     // instance norm
-    hipLaunchKernelGGL(inorm_bwd_kernel, dim3(B * H), dim3(NORM_THREADS), 0, c.st, dcat + (size_t)(2 + l * H) * P, cat_bs,
-                       cat + (size_t)(2 + l * H) * P, cat_bs, maskp, c.at(w.rstd) + (size_t)l * B * H, dy, H, P);
+    launch_inorm_bwd(P, B * H, c.st, (const float*)(dcat + (size_t)(2 + l * H) * P), cat_bs, (const float*)(cat + (size_t)(2 + l * H) * P), cat_bs,
+                     (const float*)maskp, (const float*)(c.at(w.rstd) + (size_t)l * B * H), dy, H, P);
     DPPM_TRY(check_launch("inorm_bwd"));
     // m4
     DPPM_TRY(wgrad(c, H, dy, hs, H, mm, hs, gq.m4_w, 2 * H, gq.m4_b));

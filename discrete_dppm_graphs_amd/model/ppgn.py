@@ -189,19 +189,30 @@ class Powerful(nn.Module):
         sd = dict(self.named_parameters())
         return [sd[n] for n in self.used_param_names()]
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() re-home the parameters: drop the cached pointer pack
+        self._pack_cache = None
+        return super()._apply(fn, *args, **kwargs)
+
     def _pack(self):
+        """Host-side dppm_ppgn_params over the current parameter storage.  Cached; the cache is dropped by _apply (device /
+        dtype moves), by engine.FlatState (re-homing into the flat bucket) and whenever the first or last parameter's address
+        changes.  Code that swaps `p.data` of a middle parameter by hand must set `model._pack_cache = None`."""
+        if self._pack_cache is not None:
+            key, pack, first, last = self._pack_cache
+            if first.data_ptr() == key[0] and last.data_ptr() == key[-1]:
+                return pack
         params = self._used_params()
         key = tuple(p.data_ptr() for p in params)
-        if self._pack_cache is None or self._pack_cache[0] != key:
-            tensors = {}
-            for n, p in zip(self.used_param_names(), params):
-                if not p.is_cuda:
-                    raise RuntimeError(f"parameter {n} is on {p.device}: the PPGN hot path needs the GPU (no CPU fallback); "
-                                       "call model.to('cuda')")
-                if not p.data.is_contiguous():
-                    raise RuntimeError(f"parameter {n} must be contiguous")
-                tensors[n] = p.data
-            self._pack_cache = (key, ops.ParamPack(tensors, self.num_layers, self.hidden))
+        tensors = {}
+        for n, p in zip(self.used_param_names(), params):
+            if not p.is_cuda:
+                raise RuntimeError(f"parameter {n} is on {p.device}: the PPGN hot path needs the GPU (no CPU fallback); "
+                                   "call model.to('cuda')")
+            if not p.data.is_contiguous():
+                raise RuntimeError(f"parameter {n} must be contiguous")
+            tensors[n] = p.data
+        self._pack_cache = (key, ops.ParamPack(tensors, self.num_layers, self.hidden), params[0], params[-1])
         return self._pack_cache[1]
 
     def _workspace(self, B, N, training, device, cached=None):
