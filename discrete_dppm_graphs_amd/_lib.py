@@ -33,7 +33,7 @@ class PpgnParams(C.Structure):
                 ("cat_w", C.c_void_p), ("cat_b", C.c_void_p),
                 ("after_w", C.c_void_p), ("after_b", C.c_void_p),
                 ("final_w", C.c_void_p), ("final_b", C.c_void_p),
-                ("layers_host", C.POINTER(PpgnLayer))]
+                ("layers_host", C.POINTER(PpgnLayer)), ("layer_cond", C.c_void_p)]
 
 
 _RNG = [c_f32p, C.c_uint64, C.c_uint32, C.c_uint32]   # U, seed, graph_id0, offset

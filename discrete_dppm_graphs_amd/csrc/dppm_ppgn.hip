@@ -252,6 +252,13 @@ inline void launch_inorm_bwd(int P, int nplanes, hipStream_t st, Args... args) {
   else hipLaunchKernelGGL(inorm_bwd_kernel<NORM_THREADS>, dim3(nplanes), dim3(NORM_THREADS), 0, st, args...);
 }
 
+// Powerful_Ind conditioning: plane[b][i][i] = cond[b] for i < N on the (all-zero) pad channel of a layer's input
+__global__ __launch_bounds__(256) void diag_set_kernel(float* __restrict__ plane, long bs, int N, int ld, const float* __restrict__ cond) {
+  const int b = blockIdx.x;
+  const float v = cond[b];
+  for (int i = threadIdx.x; i < N; i += blockDim.x) plane[(size_t)b * bs + (size_t)i * ld + i] = v;
+}
+
 // logits[b][i][j] = sum_o wfin[o] * (R + act)[b][o][p] + bfin     (model/ppgn.py:331-333; dropout is identity in eval)
 __global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict__ R, const float* __restrict__ act,
                                                         const float* __restrict__ wfin, const float* __restrict__ bfin,
@@ -600,6 +607,11 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     float* o2 = training ? c.at(w.o2) + (size_t)l * w.S : c.at(w.tmp[2]);
     float* mm = training ? c.at(w.mm) + (size_t)l * w.S : c.at(w.tmp[0]);
     float* y = c.at(w.tmp[3]);
+    if (pr->layer_cond) {   // variant conditioning: the layer's scalar on the diagonal of the pad channel of its input
+      float* xin = l == 0 ? c.at(w.u0) : cat + (size_t)(2 + (l - 1) * H) * P;
+      hipLaunchKernelGGL(diag_set_kernel, dim3(B), dim3(256), 0, c.st, xin + (size_t)(H - 1) * P, x_bs, N, w.ld, pr->layer_cond + (size_t)l * B);
+      DPPM_TRY(check_launch("diag_set"));
+    }
     DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
     DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, prec));
@@ -665,6 +677,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
   DPPM_REQUIRE(B > 0 && N > 0, "dppm_ppgn_backward: B=%d N=%d must be positive", B, N);
   DPPM_REQUIRE(gr->hidden == pr->hidden && gr->num_layers == pr->num_layers, "dppm_ppgn_backward: grads/params shape mismatch");
   if (dsigma) return fail(DPPM_E_UNSUPPORTED, "dppm_ppgn_backward: dsigma is not implemented yet");
+  if (pr->layer_cond) return fail(DPPM_E_UNSUPPORTED, "dppm_ppgn_backward: layer_cond (Powerful_Ind conditioning) is inference-only");
   const int H = pr->hidden, L = pr->num_layers;
   Ctx c{as_stream(stream), make_layout(B, N, H, L, 1), static_cast<float*>(workspace)};
   const Layout& w = c.w;

@@ -1,0 +1,307 @@
+"""Noise-conditioning variants of the PPGN denoiser (reference model/ppgn_indnoise.py, model/ppgn_indnoise_multdim.py,
+model/ppgn_indnoise_sincos.py; selected by `config.model.name` in {ppgn_ind, ppgn_ind_mult, ppgn_ind_sincos},
+utils/loading_utils.py:121-189) as alternative PROLOGUES on the same HIP kernels.
+
+Drop-in contract: constructor keywords, positional `forward(node_features, A, mask, noiselevel)`, output shape and
+`state_dict()` keys / shapes are the reference's, so reference-trained checkpoints of these models load and sample here.
+
+How they map onto the H-channel kernels of libdppm_hip.so
+  * Powerful_Ind / Powerful_Ind_Mult: the trunk is hidden-1 wide and every layer's input gets one more channel that holds
+    the learned scalar `times[l+1](noise)` on its diagonal.  The (hidden-1)-wide matrices are zero-padded to `hidden`
+    (pad row / column hidden-1, zero bias), which makes channel hidden-1 of every activation identically zero, and the
+    C-ABI's `layer_cond` writes the scalar on that channel's diagonal before each layer (include/dppm_hip.h).
+  * Powerful_sincos: an embedding e_l(sigma) in R^hidden is added to every position before each layer; with one sigma per
+    call (how the reference calls it) that is a change of the first-Linear biases, b + W e_l, recomputed per call.
+The embedding MLPs act on one scalar per call (O(hidden^2) work); they run as torch ops on the GPU.  Everything per position
+runs in the HIP kernels; there is no fallback.
+
+Inference only in this build: the C-ABI exports no gradient with respect to the conditioning scalars, so a forward with
+autograd enabled on trainable parameters raises NotImplementedError (no shipped config selects these models).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .ppgn import SLOPE, FeatureExtractor, PowerfulLayer, _Seq, default_precision
+
+
+class _VariantBase(nn.Module):
+    """Shared plumbing: argument checks, input preparation, workspace and padded-parameter caches."""
+
+    trunk_delta = 0          # trunk width = hidden - trunk_delta
+    input_features_expected = 2
+
+    def _init_common(self, num_layers, input_features, hidden, hidden_final, dropout_p, simplified, normalization, cat_output,
+                     adj_out, output_features, residual, spectral_norm, project_first, node_out, noise_mlp, config):
+        if normalization not in ("none", "instance", "layer", "batch"):
+            raise ValueError(f"unknown normalization {normalization!r}")
+        bad = []
+        if normalization != "instance": bad.append(f"normalization={normalization!r}")
+        if not cat_output: bad.append("cat_output=False")
+        if not adj_out: bad.append("adj_out=False")
+        if simplified: bad.append("simplified=True")
+        if residual: bad.append("residual=True")
+        if project_first: bad.append("project_first=True")
+        if node_out: bad.append("node_out=True")
+        if input_features != self.input_features_expected: bad.append(f"input_features={input_features}")
+        if output_features != 1: bad.append(f"output_features={output_features}")
+        if hidden != hidden_final: bad.append("hidden != hidden_final")
+        if hidden % 4: bad.append("hidden not a multiple of 4")
+        if spectral_norm is not None: bad.append("spectral_norm")
+        if bad:
+            raise NotImplementedError("the HIP PPGN variants implement the configuration of utils/loading_utils.py:121-189 only; "
+                                      "unsupported: " + ", ".join(bad))
+        self.num_layers, self.hidden, self.hidden_final = num_layers, hidden, hidden_final
+        self.cat_output, self.normalization, self.adj_out = cat_output, normalization, adj_out
+        self.layer_after_conv = not simplified
+        self.dropout_p = dropout_p
+        self.residual, self.project_first, self.node_out = residual, project_first, node_out
+        self.output_features = self.node_output_features = output_features
+        self.noise_mlp = noise_mlp
+        self.config = config
+        self.precision = default_precision(config)
+        self._pad_cache = None
+        self._ws_cache = {}
+
+    def get_out_dim(self):
+        return self.output_features
+
+    def forward(self, node_features, A, mask, noiselevel):
+        return self.forward_cat(A, node_features, mask, noiselevel)
+
+    def forward_cat(self, A, node_features, mask, noiselevel):
+        del node_features
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(f"{type(self).__name__} is inference-only in this build (wrap the call in torch.no_grad()); "
+                                      "training these conditioning variants is not provided")
+        return self.infer(A, mask, noiselevel).unsqueeze(-1)
+
+    # ------------------------------------------------------------------ helpers
+    def _inputs(self, A, mask, noiselevel):
+        if A.dim() == 4 and A.shape[-1] == 1:
+            A = A[..., 0]
+        if A.dim() != 3 or A.shape[-1] != A.shape[-2]:
+            raise ValueError(f"A must be [B, N, N], got {tuple(A.shape)}")
+        if not A.is_cuda:
+            raise RuntimeError(f"{type(self).__name__}.forward: A is not on the GPU; the PPGN hot path has no CPU fallback")
+        B, N, _ = A.shape
+        A = A.to(torch.float32).contiguous()
+        mask = mask.to(device=A.device, dtype=torch.float32)
+        if mask.dim() == 2:
+            mask = mask.unsqueeze(0)
+        mask = mask.expand(B, N, N).contiguous()
+        if isinstance(noiselevel, torch.Tensor):
+            sigma = noiselevel.detach().to(device=A.device, dtype=torch.float32).reshape(-1)
+        else:
+            sigma = torch.as_tensor(np.asarray(noiselevel, dtype=np.float64).reshape(-1).astype(np.float32), device=A.device)
+        if sigma.numel() == 1:
+            sigma = sigma.expand(B)
+        if sigma.numel() != B:
+            raise ValueError(f"noiselevel: {sigma.numel()} values for {B} graphs")
+        return A, mask, sigma.contiguous()
+
+    def _workspace(self, B, N, device):
+        key = (B, N, str(device))
+        if key not in self._ws_cache:
+            self._ws_cache.clear()
+            self._ws_cache[key] = ops.ppgn_workspace(B, N, self.hidden, self.num_layers, False, device)
+        return self._ws_cache[key]
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _zeros(self, *shape):
+        return torch.zeros(*shape, device=self.in_lin[0].weight.device, dtype=torch.float32)
+
+
+class Powerful_Ind(_VariantBase):
+    """reference model/ppgn_indnoise.py:124-351."""
+
+    trunk_delta = 1
+    time_mlp_final_gelu = False
+
+    def __init__(self, use_norm_layers=False, name="ppgn_indnoise", channel_num_list=None, feature_nums=None,
+                 gnn_hidden_num_list=None, num_layers=6, input_features=2, hidden=32, hidden_final=32, dropout_p=0.000001,
+                 simplified=False, n_nodes=30, config=None, normalization="none", cat_output=True, adj_out=False,
+                 output_features=1, residual=False, activation=None, spectral_norm=None, project_first=False, node_out=False,
+                 noise_mlp=False):
+        super().__init__()
+        self._init_common(num_layers, input_features, hidden, hidden_final, dropout_p, simplified, normalization, cat_output,
+                          adj_out, output_features, residual, spectral_norm, project_first, node_out, noise_mlp, config)
+        h = hidden - 1
+        # same registration order as the reference (seeded initialisation consumes the RNG identically)
+        mods = [nn.Linear(1, 4), nn.GELU(), nn.Linear(4, 1)] + ([nn.GELU()] if self.time_mlp_final_gelu else [])
+        self.time_mlp = nn.Sequential(*mods)
+        self.in_lin = _Seq(nn.Linear(input_features, h))
+        self.layer_cat_lin = _Seq(nn.Linear(h * num_layers + input_features, h))
+        self.convs = nn.ModuleList([])
+        self.bns = nn.ModuleList([])
+        self.times = nn.ModuleList([_Seq(nn.Linear(1, 1))])
+        for _ in range(num_layers):
+            self.convs.append(PowerfulLayer(hidden, h, 2))
+            self.times.append(_Seq(nn.Linear(1, 1)))
+        self.feature_extractors = nn.ModuleList([FeatureExtractor(h, hidden_final) for _ in range(num_layers)])
+        self.after_conv = _Seq(nn.Linear(hidden_final - 1, hidden_final - 1))
+        self.final_lin = _Seq(nn.Linear(hidden_final - 1, output_features))
+
+    def _padded_pack(self):
+        """The (hidden-1)-wide matrices zero-padded to `hidden` (module docstring), rebuilt when a parameter changes."""
+        sig = self._signature()
+        if self._pad_cache is not None and self._pad_cache[0] == sig:
+            return self._pad_cache[1]
+        H, h, L = self.hidden, self.hidden - 1, self.num_layers
+        sd = {k: v.detach() for k, v in self.named_parameters()}
+        t = {}
+
+        def pad(name, rows, cols=None):
+            src = sd[name]
+            dst = self._zeros(rows) if cols is None else self._zeros(rows, cols)
+            if cols is None:
+                dst[:src.shape[0]] = src
+            else:
+                dst[:src.shape[0], :src.shape[1]] = src
+            return dst
+
+        t["in_lin.0.weight"], t["in_lin.0.bias"] = pad("in_lin.0.weight", H, 2), pad("in_lin.0.bias", H)
+        for l in range(L):
+            for m in ("m1", "m2"):
+                for k in ("0", "2"):
+                    t[f"convs.{l}.{m}.{k}.weight"] = pad(f"convs.{l}.{m}.{k}.weight", H, H)
+                    t[f"convs.{l}.{m}.{k}.bias"] = pad(f"convs.{l}.{m}.{k}.bias", H)
+            w4 = sd[f"convs.{l}.m4.0.weight"]            # [h, h + H]: cat(contraction (h channels), layer input (H channels))
+            p4 = self._zeros(H, 2 * H)
+            p4[:h, :h] = w4[:, :h]
+            p4[:h, H:] = w4[:, h:]
+            t[f"convs.{l}.m4.0.weight"], t[f"convs.{l}.m4.0.bias"] = p4, pad(f"convs.{l}.m4.0.bias", H)
+        wc = sd["layer_cat_lin.0.weight"]                # [h, 2 + L h]
+        pc = self._zeros(H, 2 + L * H)
+        pc[:h, :2] = wc[:, :2]
+        for l in range(L):
+            pc[:h, 2 + l * H:2 + l * H + h] = wc[:, 2 + l * h:2 + (l + 1) * h]
+        t["layer_cat_lin.0.weight"], t["layer_cat_lin.0.bias"] = pc, pad("layer_cat_lin.0.bias", H)
+        t["after_conv.0.weight"], t["after_conv.0.bias"] = pad("after_conv.0.weight", H, H), pad("after_conv.0.bias", H)
+        t["final_lin.0.weight"], t["final_lin.0.bias"] = pad("final_lin.0.weight", 1, H), sd["final_lin.0.bias"].clone()
+        pack = ops.ParamPack(t, L, H)
+        self._pad_cache = (sig, pack)
+        return pack
+
+    @torch.no_grad()
+    def infer(self, A, mask, noiselevel, out=None):
+        A, mask, sigma = self._inputs(A, mask, noiselevel)
+        B, N, _ = A.shape
+        cond = sigma.view(B, 1)
+        if self.noise_mlp:      # ppgn_indnoise.py:279-287
+            cond = self.time_mlp(cond)
+            nin = self.times[0](cond)
+        else:
+            nin = cond
+        layer_cond = torch.cat([self.times[l + 1](cond) for l in range(self.num_layers)], dim=1).t().contiguous()   # [L, B]
+        pack = self._padded_pack()
+        pack.set_layer_cond(layer_cond)
+        return ops.ppgn_forward(pack, A, mask, nin.reshape(B).contiguous(), self._workspace(B, N, A.device), training=False, out=out,
+                                precision=self.precision)
+
+
+class SinusoidalPosEmb(nn.Module):
+    """reference model/ppgn_indnoise_sincos.py:89-100."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x):
+        half_dim = self.dim // 2
+        emb = math.log(10000) / (half_dim - 1)
+        emb = torch.exp(torch.arange(half_dim, device=x.device) * -emb)
+        emb = x[:, None] * emb[None, :]
+        return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
+class Powerful_sincos(_VariantBase):
+    """reference model/ppgn_indnoise_sincos.py:102-262 (runs only with noise_mlp=True, as in the reference)."""
+
+    input_features_expected = 1
+
+    def __init__(self, use_norm_layers=False, name="ppgn_sincos", channel_num_list=None, feature_nums=None,
+                 gnn_hidden_num_list=None, num_layers=6, input_features=1, hidden=32, hidden_final=32, dropout_p=0.000001,
+                 simplified=False, n_nodes=30, config=None, normalization="none", cat_output=True, adj_out=False,
+                 output_features=1, residual=False, activation=None, spectral_norm=None, project_first=False, node_out=False,
+                 noise_mlp=False):
+        super().__init__()
+        self._init_common(num_layers, input_features, hidden, hidden_final, dropout_p, simplified, normalization, cat_output,
+                          adj_out, output_features, residual, spectral_norm, project_first, node_out, noise_mlp, config)
+        act = nn.LeakyReLU(negative_slope=SLOPE)
+        self.time_mlp = nn.Sequential(SinusoidalPosEmb(hidden), nn.Linear(hidden, 4 * hidden), act, nn.Linear(4 * hidden, hidden), act)
+        self.in_lin = _Seq(nn.Linear(1, hidden))
+        self.layer_cat_lin = _Seq(nn.Linear(hidden * num_layers + input_features, hidden))
+        self.convs = nn.ModuleList([])
+        self.bns = nn.ModuleList([])
+        self.times = nn.ModuleList([_Seq(nn.Linear(hidden, 1))])
+        for _ in range(num_layers):
+            self.convs.append(PowerfulLayer(hidden, hidden, 2))
+            self.times.append(_Seq(nn.Linear(hidden, hidden)))
+        self.feature_extractors = nn.ModuleList([FeatureExtractor(hidden, hidden_final) for _ in range(num_layers)])
+        self.after_conv = _Seq(nn.Linear(hidden_final, hidden_final))
+        self.final_lin = _Seq(nn.Linear(hidden_final, output_features))
+
+    def _eff_pack(self):
+        """Weights as the kernels expect them; the biases that absorb the embedding live in private buffers filled per call."""
+        sig = self._signature()
+        if self._pad_cache is not None and self._pad_cache[0] == sig:
+            return self._pad_cache[1], self._pad_cache[2]
+        H, L = self.hidden, self.num_layers
+        sd = {k: v.detach() for k, v in self.named_parameters()}
+        t, eff = {}, {}
+        w_in = self._zeros(H, 2)
+        w_in[:, 0] = sd["in_lin.0.weight"][:, 0]
+        t["in_lin.0.weight"] = w_in
+        t["in_lin.0.bias"] = eff["in"] = self._zeros(H)
+        for l in range(L):
+            for m in ("m1", "m2"):
+                t[f"convs.{l}.{m}.0.weight"] = sd[f"convs.{l}.{m}.0.weight"].contiguous()
+                t[f"convs.{l}.{m}.0.bias"] = eff[f"{l}.{m}"] = self._zeros(H)
+                t[f"convs.{l}.{m}.2.weight"] = sd[f"convs.{l}.{m}.2.weight"].contiguous()
+                t[f"convs.{l}.{m}.2.bias"] = sd[f"convs.{l}.{m}.2.bias"].contiguous()
+            t[f"convs.{l}.m4.0.weight"] = sd[f"convs.{l}.m4.0.weight"].contiguous()
+            t[f"convs.{l}.m4.0.bias"] = eff[f"{l}.m4"] = self._zeros(H)
+        wc = sd["layer_cat_lin.0.weight"]                # [H, 1 + L H]: first column acts on (A + e_0)
+        pc = self._zeros(H, 2 + L * H)
+        pc[:, 0] = wc[:, 0]
+        pc[:, 2:] = wc[:, 1:]
+        t["layer_cat_lin.0.weight"] = pc
+        t["layer_cat_lin.0.bias"] = eff["cat"] = self._zeros(H)
+        for n in ("after_conv.0.weight", "after_conv.0.bias", "final_lin.0.weight", "final_lin.0.bias"):
+            t[n] = sd[n].contiguous()
+        pack = ops.ParamPack(t, L, H)
+        self._pad_cache = (sig, pack, eff)
+        return pack, eff
+
+    @torch.no_grad()
+    def infer(self, A, mask, noiselevel, out=None):
+        if not self.noise_mlp:
+            raise RuntimeError("Powerful_sincos needs noise_mlp=True (the reference reads an undefined variable otherwise, "
+                               "model/ppgn_indnoise_sincos.py:198-203)")
+        A, mask, sigma = self._inputs(A, mask, noiselevel)
+        B, N, _ = A.shape
+        if B > 1 and not bool((sigma == sigma[0]).all()):
+            raise NotImplementedError("Powerful_sincos: one noise level per call (as the reference passes it); per-graph levels "
+                                      "would need per-graph biases")
+        pack, eff = self._eff_pack()
+        sd = {k: v.detach() for k, v in self.named_parameters()}
+        pre = self.time_mlp(sigma[:1])                                   # [1, H]
+        e0 = F.leaky_relu(self.times[0](pre), SLOPE).reshape(())         # scalar added to A before in_lin
+        torch.add(sd["in_lin.0.bias"], sd["in_lin.0.weight"][:, 0] * e0, out=eff["in"])
+        torch.add(sd["layer_cat_lin.0.bias"], sd["layer_cat_lin.0.weight"][:, 0] * e0, out=eff["cat"])
+        H = self.hidden
+        for l in range(self.num_layers):
+            e = F.leaky_relu(self.times[l + 1](pre), SLOPE).reshape(H)   # added to every channel before layer l
+            for m in ("m1", "m2"):
+                torch.addmv(sd[f"convs.{l}.{m}.0.bias"], sd[f"convs.{l}.{m}.0.weight"], e, out=eff[f"{l}.{m}"])
+            torch.addmv(sd[f"convs.{l}.m4.0.bias"], sd[f"convs.{l}.m4.0.weight"][:, H:], e, out=eff[f"{l}.m4"])
+        zero_sigma = torch.zeros(B, device=A.device, dtype=torch.float32)   # the sigma*I input channel has zero weight here
+        return ops.ppgn_forward(pack, A, mask, zero_sigma, self._workspace(B, N, A.device), training=False, out=out,
+                                precision=self.precision)

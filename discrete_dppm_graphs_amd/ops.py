@@ -191,7 +191,7 @@ def expected_shapes(num_layers, H):
 class ParamPack:
     """Host-side dppm_ppgn_params built from a {state_dict name: cuda tensor} mapping.  Keeps the tensors alive."""
 
-    def __init__(self, tensors, num_layers, hidden):
+    def __init__(self, tensors, num_layers, hidden, layer_cond=None):
         shapes = expected_shapes(num_layers, hidden)
         self.tensors = {}
         for name, shape in shapes.items():
@@ -208,6 +208,17 @@ class ParamPack:
         for field, name in TOP_FIELDS:
             setattr(self.struct, field, self.tensors[name].data_ptr())
         self.struct.layers_host = C.cast(self.layers, C.POINTER(PpgnLayer))
+        self.layer_cond = None
+        self.set_layer_cond(layer_cond)
+
+    def set_layer_cond(self, layer_cond):
+        """[L, B] float32 on the device (Powerful_Ind conditioning, include/dppm_hip.h) or None."""
+        if layer_cond is not None:
+            if layer_cond.dim() != 2 or layer_cond.shape[0] != self.struct.num_layers:
+                raise ValueError(f"layer_cond: shape {tuple(layer_cond.shape)}, expected [{self.struct.num_layers}, B]")
+            _chk(layer_cond, "layer_cond")
+        self.layer_cond = layer_cond
+        self.struct.layer_cond = layer_cond.data_ptr() if layer_cond is not None else None
 
     def ref(self):
         return C.byref(self.struct)
@@ -225,6 +236,8 @@ def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None, prec
     B, N, _ = A.shape
     mask = _chk(mask, "mask", (B, N, N))
     sigma = _chk(sigma, "sigma", (B,))
+    if pack.layer_cond is not None and pack.layer_cond.shape[1] != B:
+        raise ValueError(f"layer_cond holds {pack.layer_cond.shape[1]} graphs, the batch has {B}")
     _chk(workspace, "workspace")
     logits = out if out is not None else torch.empty(B, N, N, device=A.device, dtype=torch.float32)
     _chk(logits, "out", (B, N, N))

@@ -137,6 +137,12 @@ typedef struct dppm_ppgn_params {
   float* after_w; float* after_b; /* after_conv.0.*   [H][H], [H] */
   float* final_w; float* final_b; /* final_lin.0.*    [1][H], [1] */
   const dppm_ppgn_layer* layers_host; /* HOST array of L entries (entries hold device pointers) */
+  /* Per-layer noise conditioning of the Powerful_Ind / Powerful_Ind_Mult variants (model/ppgn_indnoise.py:306-315,
+   * model/ppgn_indnoise_multdim.py: the learned scalar of layer l on the diagonal of an extra input channel).  Nullable.
+   * [L][B] floats on the device: before layer l runs, layer_cond[l][b] is written on the whole diagonal of channel H-1 of its
+   * INPUT planes.  The caller passes the variant's (H-1)-wide matrices zero-padded to H (pad row / column H-1, zero bias), so
+   * that channel is identically zero everywhere else.  Inference only: dppm_ppgn_backward rejects a non-null layer_cond. */
+  const float* layer_cond;
 } dppm_ppgn_params;
 
 /* Bytes of workspace dppm_ppgn_forward needs; with training != 0 it also keeps what dppm_ppgn_backward reads. */

@@ -122,3 +122,87 @@ def init_weights(num_layers, hidden, seed, noise_mlp=False):
         W["time_mlp.0.weight"], W["time_mlp.0.bias"] = lin(4, 1)
         W["time_mlp.2.weight"], W["time_mlp.2.bias"] = lin(1, 4)
     return W
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Noise-conditioning variants.  Pinned against tests/golden/g6_variant_*.npz, produced by the
+# reference's own Powerful_Ind / Powerful_Ind_Mult / Powerful_sincos (tests/golden/gen_golden_variants.py).
+# ---------------------------------------------------------------------------------------------------------
+def _sig_vec(noiselevel, B, dtype):
+    sig = torch.as_tensor(np.asarray(noiselevel, dtype=np.float64).reshape(-1).astype(np.float32)).to(dtype)
+    return sig.expand(B) if sig.numel() == 1 else sig
+
+
+def _readout(W, outs):
+    out = torch.cat(outs, dim=-1)
+    out = _lin(out, W["layer_cat_lin.0.weight"], W["layer_cat_lin.0.bias"])
+    out = out + F.leaky_relu(_lin(out, W["after_conv.0.weight"], W["after_conv.0.bias"]), SLOPE)
+    return _lin(out, W["final_lin.0.weight"], W["final_lin.0.bias"])
+
+
+def powerful_ind_forward(W, A, mask, noiselevel, num_layers, noise_mlp=False, mult=False, dtype=torch.float32):
+    """model/ppgn_indnoise.py:271-351 (Powerful_Ind) and model/ppgn_indnoise_multdim.py:169-244 (Powerful_Ind_Mult, mult=True:
+    its time_mlp ends in a second GELU, :112-117).  Trunk width hidden-1; before every layer the learned scalar
+    times[l+1](noise) goes on the diagonal of an extra channel (padded diagonal entries included)."""
+    A = torch.as_tensor(A, dtype=dtype)
+    mask = torch.as_tensor(mask, dtype=dtype)
+    B, N, _ = A.shape
+    mask4 = mask[..., None]
+    cond = _sig_vec(noiselevel, B, dtype).view(B, 1)
+
+    def diag(v):   # [B,1] -> [B,N,N,1] with v_b on the whole diagonal
+        return torch.diag_embed(v.expand(B, N))[..., None]
+
+    if noise_mlp:   # ppgn_indnoise.py:279-287
+        cond = _lin(F.gelu(_lin(cond, W["time_mlp.0.weight"], W["time_mlp.0.bias"])), W["time_mlp.2.weight"], W["time_mlp.2.bias"])
+        if mult:
+            cond = F.gelu(cond)
+        nin = _lin(cond, W["times.0.0.weight"], W["times.0.0.bias"])
+    else:
+        nin = cond
+    u = torch.cat([A[..., None], diag(nin)], dim=-1)
+    outs = [u]
+    u = _lin(u, W["in_lin.0.weight"], W["in_lin.0.bias"])
+    for l in range(num_layers):
+        nl = _lin(cond, W[f"times.{l + 1}.0.weight"], W[f"times.{l + 1}.0.bias"])
+        u = torch.cat([u, diag(nl)], dim=-1)
+        u = powerful_layer(u, mask4, W, l)
+        u = masked_instance_norm2d(u, mask4) * mask4
+        outs.append(u)
+    return _readout(W, outs)
+
+
+def sinusoidal_pos_emb(t, dim):
+    """model/ppgn_indnoise_sincos.py:89-100."""
+    half = dim // 2
+    f = torch.exp(torch.arange(half, dtype=t.dtype) * -(np.log(10000) / (half - 1)))
+    e = t[:, None] * f[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def sincos_embeddings(W, noiselevel, B, num_layers, hidden, dtype=torch.float32):
+    """-> [e_0 [B,1], e_1 .. e_L [B,H]]: act(times[l](time_mlp(sigma)))  (ppgn_indnoise_sincos.py:198-203, :215-217)."""
+    t = _sig_vec(noiselevel, B, dtype)
+    pre = sinusoidal_pos_emb(t, hidden)
+    pre = F.leaky_relu(_lin(pre, W["time_mlp.1.weight"], W["time_mlp.1.bias"]), SLOPE)
+    pre = F.leaky_relu(_lin(pre, W["time_mlp.3.weight"], W["time_mlp.3.bias"]), SLOPE)
+    return [F.leaky_relu(_lin(pre, W[f"times.{l}.0.weight"], W[f"times.{l}.0.bias"]), SLOPE) for l in range(num_layers + 1)]
+
+
+def powerful_sincos_forward(W, A, mask, noiselevel, num_layers, hidden, dtype=torch.float32):
+    """model/ppgn_indnoise_sincos.py:189-262 (Powerful_sincos; the reference only runs with noise_mlp=True).  A learned
+    embedding of sigma is ADDED to every channel at every position before in_lin and before each layer."""
+    A = torch.as_tensor(A, dtype=dtype)
+    mask = torch.as_tensor(mask, dtype=dtype)
+    B, N, _ = A.shape
+    mask4 = mask[..., None]
+    emb = sincos_embeddings(W, noiselevel, B, num_layers, hidden, dtype)
+    u = A[..., None] + emb[0][:, None, None, :]
+    outs = [u]
+    u = _lin(u, W["in_lin.0.weight"], W["in_lin.0.bias"])
+    for l in range(num_layers):
+        u = u + emb[l + 1][:, None, None, :]
+        u = powerful_layer(u, mask4, W, l)
+        u = masked_instance_norm2d(u, mask4) * mask4
+        outs.append(u)
+    return _readout(W, outs)
