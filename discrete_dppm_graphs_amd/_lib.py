@@ -67,6 +67,10 @@ SIGNATURES = {
     "dppm_linear_wgrad": (C.c_int, [c_f32p, C.c_long, c_f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                     c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "dppm_inorm_fwd": (C.c_int, [c_f32p, C.c_long, c_f32p, c_f32p, C.c_long, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_stream]),
+    "dppm_graph_stats": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f32p, c_f32p, c_stream]),
+    "dppm_mmd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dppm_mmd_gaussian_emd": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_double, C.c_double, c_f64p, C.c_void_p,
+                                        C.c_size_t, c_stream]),
     "dppm_prof_begin": (C.c_int, [C.c_int]),
     "dppm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
     "dppm_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,

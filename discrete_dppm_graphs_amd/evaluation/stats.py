@@ -1,7 +1,12 @@
-"""Boundary to the reference's evaluation side branch (evaluation/stats.py), which is OUT OF SCOPE for the accelerated
-hot path (CPU graph statistics on networkx / pyemd / ORCA).  Only what the samplers call is provided:
-`adjs_to_graphs` and an `eval_graph_list` hook.  Register the reference's own evaluator (or any other) with
-`set_evaluator(fn)`; the default computes a degree-histogram MMD (Gaussian-TV kernel) with numpy only."""
+"""Boundary to the reference's evaluation side branch (evaluation/stats.py).  What the samplers call is provided:
+`adjs_to_graphs`, `eval_torch_batch` and an `eval_graph_list` hook.
+
+On a GPU the default evaluator computes the reference's `degree` and `cluster` MMDs (degree / clustering-coefficient
+histograms, Gaussian-EMD kernel, evaluation/stats.py:41-69, :140-186, evaluation/mmd.py:32-41, :90-106) with the HIP
+kernels of csrc/dppm_stats.hip, so periodic model selection does not stall training on
+networkx / pyemd loops.  The `orbit` MMD (ORCA subprocess) and the SBM likelihood (graph_tool) stay out of scope; register
+the reference's own evaluator (or any other) with `set_evaluator(fn)` to get them.  Without a GPU the default is a
+numpy degree-histogram MMD (Gaussian-TV kernel)."""
 import numpy as np
 
 _EVALUATOR = None
@@ -52,7 +57,46 @@ def degree_mmd(ref, pred):
     return float(k(a, a) + k(b, b) - 2 * k(a, b))
 
 
+def eval_torch_batch(ref_batch, pred_batch, methods=None, bins=100):
+    """reference evaluation/stats.py:340-344 on the device: ref_batch / pred_batch are [G, N, N] adjacency tensors (cuda).
+    Returns {'degree': mmd, 'cluster': mmd} as python floats (one host sync at the end)."""
+    from .. import ops
+    methods = list(methods) if methods is not None else ['degree', 'cluster']
+    n = max(ref_batch.shape[-1], pred_batch.shape[-1])
+
+    import torch
+
+    def hist(batch):
+        if batch.shape[-1] != n:     # pad to a common node count so that degree histograms share their support
+            batch = torch.nn.functional.pad(batch, (0, n - batch.shape[-1], 0, n - batch.shape[-1]))
+        return ops.graph_stats(batch, bins=bins)
+    d1, c1 = hist(ref_batch)
+    d2, c2 = hist(pred_batch)
+    out = {}
+    if 'degree' in methods:
+        out['degree'] = ops.mmd_gaussian_emd(d1, d2, sigma=1.0, distance_scaling=1.0)[0]
+    if 'cluster' in methods:
+        out['cluster'] = ops.mmd_gaussian_emd(c1, c2, sigma=1.0 / 10, distance_scaling=float(bins))[0]
+    return {k: float(v.item()) for k, v in out.items()}
+
+
+def _dense_batch(graphs):
+    """list of networkx graphs / dense numpy adjacencies -> [G, n, n] float32 array (zero padded)."""
+    import networkx as nx
+    mats = [np.asarray(g, dtype=np.float32) if isinstance(g, np.ndarray) else nx.to_numpy_array(g, dtype=np.float32) for g in graphs]
+    n = max(max(m.shape[0] for m in mats), 1)
+    out = np.zeros((len(mats), n, n), np.float32)
+    for i, m in enumerate(mats):
+        out[i, :m.shape[0], :m.shape[1]] = m
+    return out
+
+
 def eval_graph_list(graph_ref_list, graph_pred_list, methods=None):
     if _EVALUATOR is not None:
         return _EVALUATOR(graph_ref_list, graph_pred_list, methods=methods)
+    import torch
+    if torch.cuda.is_available():
+        want = [m for m in (methods or ['degree', 'cluster']) if m in ('degree', 'cluster')]
+        return eval_torch_batch(torch.from_numpy(_dense_batch(graph_ref_list)).cuda(),
+                                torch.from_numpy(_dense_batch(graph_pred_list)).cuda(), methods=want)
     return {"degree": degree_mmd(graph_ref_list, graph_pred_list)}

@@ -344,6 +344,36 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
                              beta2, eps, weight_decay, int(step), grad_scale, _stream()), "dppm_adam_step")
 
 
+# ------------------------------------------------------------------------------------------------- graph statistics
+def graph_stats(adj, bins=100):
+    """adj [B, N, N] on the GPU -> (deg_hist [B, N], clus_hist [B, bins]) float32 counts (include/dppm_hip.h)."""
+    adj = _chk(_f32c(adj), "adj")
+    B, N, N2 = adj.shape
+    if N != N2:
+        raise ValueError(f"adj must be [B, N, N], got {tuple(adj.shape)}")
+    edges = torch.as_tensor(np.linspace(0.0, 1.0, bins + 1), device=adj.device)      # numpy.histogram's float64 edges
+    deg = torch.empty(B, N, device=adj.device, dtype=torch.float32)
+    clus = torch.empty(B, bins, device=adj.device, dtype=torch.float32)
+    check(lib.dppm_graph_stats(_ptr(adj), B, N, int(bins), _ptr(edges), _ptr(deg), _ptr(clus), _stream()), "dppm_graph_stats")
+    return deg, clus
+
+
+def mmd_gaussian_emd(h1, h2, sigma=1.0, distance_scaling=1.0):
+    """h1 [n1, bins], h2 [n2, bins] (counts) -> float64 tensor {mmd, k11, k22, k12} on the device."""
+    h1 = _chk(_f32c(h1), "h1")
+    h2 = _chk(_f32c(h2), "h2")
+    if h1.dim() != 2 or h2.dim() != 2 or h1.shape[1] != h2.shape[1]:
+        raise ValueError("mmd_gaussian_emd: histograms must be [n, bins] with equal bins")
+    n1, bins = h1.shape
+    n2 = h2.shape[0]
+    nbytes = lib.dppm_mmd_workspace_bytes(n1, n2)
+    ws = torch.empty(max(nbytes, 8) // 8, device=h1.device, dtype=torch.float64)
+    out = torch.empty(4, device=h1.device, dtype=torch.float64)
+    check(lib.dppm_mmd_gaussian_emd(_ptr(h1), n1, _ptr(h2), n2, bins, C.c_double(sigma), C.c_double(distance_scaling), _ptr(out),
+                                    _ptr(ws), C.c_size_t(nbytes), _stream()), "dppm_mmd_gaussian_emd")
+    return out
+
+
 PROF_CLASSES = ("linear_gemm", "plane_matmul", "wgrad_gemm", "inorm", "wstat_mlp2", "wstat_sum2", "wstat_cols")
 
 

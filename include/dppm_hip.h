@@ -218,6 +218,27 @@ int dppm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Graph statistics for model selection (the step after sampling; the reference does it with networkx / pyemd on the CPU)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Degree and clustering-coefficient histograms of B graphs given as dense adjacencies adj[B][N][N] (entries > 0.5 are edges,
+ * the diagonal is ignored, isolated nodes do not belong to the graph and an edgeless graph counts as one isolated node,
+ * as evaluation/stats.py:276-286 adjs_to_graphs builds them).  deg_hist[B][N]: number of nodes of degree d
+ * (nx.degree_histogram, zero-padded to N entries); clus_hist[B][bins]: numpy.histogram(nx.clustering(G).values(),
+ * bins, range=(0, 1)) with edges_dev = the bins+1 float64 edges numpy.linspace(0, 1, bins+1) gives (device array).
+ * N <= 1024.  Replaces the histogram loops of evaluation/stats.py:41-69 (degree_stats) and :140-186 (clustering_stats). */
+int dppm_graph_stats(const float* adj, int B, int N, int bins, const double* edges_dev, float* deg_hist, float* clus_hist,
+                     void* stream);
+
+/* MMD^2 between two sets of histograms (rows of h1[n1][bins], h2[n2][bins]; raw counts, normalised here) with the
+ * Gaussian-EMD kernel k = exp(-emd^2 / (2 sigma^2)), emd = first Wasserstein distance with ground distance
+ * |i - j| / distance_scaling.  out4 (device doubles): {mmd, mean k(1,1), mean k(2,2), mean k(1,2)}.
+ * Replaces evaluation/mmd.py:90-106 compute_mmd with :32-41 gaussian_emd (pyemd on the toeplitz distance matrix). */
+size_t dppm_mmd_workspace_bytes(int n1, int n2);
+int dppm_mmd_gaussian_emd(const float* h1, int n1, const float* h2, int n2, int bins, double sigma, double distance_scaling,
+                          double* out4, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (no counterpart in the reference; used by bench.py only).
  * dppm_prof_begin arms per-launch HIP-event timing of the GEMM-family and norm kernels (events are recorded on the
  * stream each kernel is launched on); dppm_prof_end waits for them and returns, per kernel class
