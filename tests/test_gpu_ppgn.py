@@ -342,3 +342,37 @@ def test_adam_matches_torch(ops):
         opt.step()
         ops.adam_step(pd, g.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_split_wgrad_opt_in():
+    """DPPM_WGRAD_BF16X3=1 (read once per process, hence the child process): weight gradients with split-bf16 products stay within
+    1e-3 of the exact-float32 kernels' on a well-conditioned H = 128 network."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from tests.test_gpu_ppgn import rand_case, run_gpu
+from discrete_dppm_graphs_amd import ops
+from oracle import ppgn as op
+rng = np.random.default_rng(1)
+A, mask = rand_case(rng, 2, 72)
+W = op.init_weights(2, 128, seed=4)
+R = rng.normal(size=A.shape).astype(np.float32) * mask
+_, g = run_gpu(ops, W, A, mask, [0.1, 0.3], 2, 128, dlogits=R)
+np.savez(sys.argv[1], **g)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = []
+    for env in ({}, {"DPPM_WGRAD_BF16X3": "1"}):
+        with tempfile.NamedTemporaryFile(suffix=".npz") as f:
+            subprocess.check_call([sys.executable, "-c", code, f.name], env={**os.environ, **env})
+            outs.append(dict(np.load(f.name)))
+    gmax = max(np.abs(v).max() for v in outs[0].values())
+    differs = False
+    for k in outs[0]:
+        scale = max(np.abs(outs[0][k]).max(), 2e-2 * gmax)
+        err = np.abs(outs[0][k] - outs[1][k]).max()
+        assert err <= 1e-3 * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
+        differs |= err > 0
+    assert differs       # the switch did select the other kernel
