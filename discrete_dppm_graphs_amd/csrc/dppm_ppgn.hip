@@ -456,10 +456,8 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
 }
 int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
   if (use_wstat(M) && Nw == WS_H && c.w.slab_floats >= ws_wgrad_scratch_floats()) {   // register-resident split-K form (dppm_wgrad.h)
-    // Opt-in (DPPM_WGRAD_BF16X3=1): split-bf16 products in the weight gradients.  22.1 -> 15.4 ms per N=200 training step
-    // (+5 % steps/s), but on the ill-conditioned network of test_backward_kinkfree_h128 the gradients land 6x further from
-    // float64 than torch-float32 does (cancelling sums of 1.3 M terms), so exact float32 stays the default.
-    static const bool split = getenv("DPPM_WGRAD_BF16X3") != nullptr;
+    // three-piece split products on the bf16 pipe (float32-grade, dppm_wgrad.h); DPPM_WGRAD_F32=1 = exact-f32 MFMAs (A/B switch)
+    static const bool split = getenv("DPPM_WGRAD_F32") == nullptr;
     return ws_wgrad(dY, dy_bs, X, x_bs, c.w.B, c.w.P, dW, ldo, db, c.at(c.w.slabs), c.st, split);
   }
   return wgrad_raw(Geo{c.w.B, c.w.P, c.st}, M, dY, dy_bs, Nw, X, x_bs, dW, ldo, db, c.at(c.w.slabs), c.w.slab_floats, c.at(c.w.rsum));

@@ -126,53 +126,59 @@ __global__ __launch_bounds__(WG_THREADS, 4) void ws_wgrad_kernel(const WgArgs a)
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Split-bf16 form of the same product (see dppm_wsplit.h: x = hi + lo, three bf16 MFMAs per product, float32
-// accumulation).  K is the position index, which is contiguous in both operands' natural layout, so a lane's MFMA fragment
-// (8 consecutive positions of one channel) needs no transpose: a staged tile is an image [128 channels][64 positions] of
-// bf16 (128-byte rows), 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 for the
-// {0-3,12-15,20-27},... lane groups; a row's 16 staging lanes write its whole 128 bytes).  A weight gradient is a leaf of
-// the backward pass: its products are not propagated further, so the 2^-16 product error stays at ~4e-6 of the summed
-// terms' magnitude.  3/16 of the matrix time: 0.39 -> 0.27 ms per gradient, HBM-bound.  Opt-in (see wgrad() in
-// dppm_ppgn.hip): when the 1.3 M terms cancel strongly the result is 6x further from float64 than exact-f32 products.
+// Three-piece split form of the same product on the bf16 matrix pipe: every float32 operand is written as
+//   x = hi + mid + lo,  hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (3 x 8 significand bits = all 24)
+// and a product is hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid on v_mfma_f32_16x16x32_bf16 with float32 accumulation:
+// the dropped terms are <= 2^-24 of the product, i.e. float32-grade, at 6/16 of the f32 MFMA time, which this HBM-bound
+// kernel does not feel.  (The two-piece form of dppm_wsplit.h, 2^-16 per product, is NOT good enough here: where the 1.3 M
+// summed terms cancel, it landed 6x further from float64 than exact-f32 products; measured on test_backward_kinkfree_h128.)
+// K is the position index, contiguous in both operands' natural layout, so a lane's MFMA fragment (8 consecutive positions
+// of one channel) needs no transpose: a staged tile is an image [128 channels][32 positions] of bf16 per piece (64-byte
+// rows, chunk swizzle c ^ ((-(r >> 2)) & 3): conflict-free ds_read_b128; 16 staging lanes write two whole rows).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned wg3_off(unsigned row, unsigned c) { return row * 128 + ((c ^ ((row >> 1) & 7u)) << 4); }
+constexpr int W6_TP = 32;                      // positions per tile = one MFMA K step
+constexpr int W6_IMG = WS_H * W6_TP * 2;       // bytes of one piece image (8 KB)
 
-struct Wg3Pre { float4 a, b, c, d; };
+__device__ __forceinline__ unsigned wg6_off(unsigned row, unsigned c) { return row * 64 + ((c ^ ((0u - (row >> 2)) & 3u)) << 4); }
 
-__device__ __forceinline__ void wg3_issue(Wg3Pre& q, const float* __restrict__ Xt, unsigned P, unsigned o) {
+struct Wg6Pre { float4 a, b; };
+
+__device__ __forceinline__ void wg6_issue(Wg6Pre& q, const float* __restrict__ Xt, unsigned P, unsigned o) {
   q.a = *reinterpret_cast<const float4*>(Xt + o);
-  q.b = *reinterpret_cast<const float4*>(Xt + (size_t)32 * P + o);
-  q.c = *reinterpret_cast<const float4*>(Xt + (size_t)64 * P + o);
-  q.d = *reinterpret_cast<const float4*>(Xt + (size_t)96 * P + o);
+  q.b = *reinterpret_cast<const float4*>(Xt + (size_t)64 * P + o);
 }
-__device__ __forceinline__ void wg3_put(char* __restrict__ img, unsigned off, const float4& v, bool in) {
-  unsigned h01, l01, h23, l23;
-  w3_split2<3>(in ? v.x : 0.f, in ? v.y : 0.f, h01, l01);
-  w3_split2<3>(in ? v.z : 0.f, in ? v.w : 0.f, h23, l23);
+__device__ __forceinline__ void wg6_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = w3_pack(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = w3_pack(r0, r1);
+  l = w3_pack(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ void wg6_put(char* __restrict__ img, unsigned off, const float4& v, bool in) {
+  unsigned h01, m01, l01, h23, m23, l23;
+  wg6_split2(in ? v.x : 0.f, in ? v.y : 0.f, h01, m01, l01);
+  wg6_split2(in ? v.z : 0.f, in ? v.w : 0.f, h23, m23, l23);
   *reinterpret_cast<uint2*>(img + off) = make_uint2(h01, h23);
-  *reinterpret_cast<uint2*>(img + W3_IMG + off) = make_uint2(l01, l23);
+  *reinterpret_cast<uint2*>(img + W6_IMG + off) = make_uint2(m01, m23);
+  *reinterpret_cast<uint2*>(img + 2 * W6_IMG + off) = make_uint2(l01, l23);
 }
-// thread (row = tid >> 4 (+ 32 v), position quad q = tid & 15): 4 positions = 8 bytes, chunk q >> 1, half q & 1
-__device__ __forceinline__ void wg3_land(const Wg3Pre& p, char* __restrict__ img, int tid, bool in) {
-  const unsigned row = tid >> 4, q = tid & 15, hb = (q & 1) * 8, c = q >> 1;
-  wg3_put(img, wg3_off(row, c) + hb, p.a, in);
-  wg3_put(img, wg3_off(row + 32, c) + hb, p.b, in);
-  wg3_put(img, wg3_off(row + 64, c) + hb, p.c, in);
-  wg3_put(img, wg3_off(row + 96, c) + hb, p.d, in);
+// thread (row = tid >> 3 (+ 64), position quad q = tid & 7): 4 positions = 8 bytes, chunk q >> 1, half q & 1
+__device__ __forceinline__ void wg6_land(const Wg6Pre& p, char* __restrict__ img, int tid, bool in) {
+  const unsigned row = tid >> 3, q = tid & 7, hb = (q & 1) * 8, c = q >> 1;
+  wg6_put(img, wg6_off(row, c) + hb, p.a, in);
+  wg6_put(img, wg6_off(row + 64, c) + hb, p.b, in);
 }
 
 template <bool WITH_DB>
-__global__ __launch_bounds__(WG_THREADS, 4) void ws3_wgrad_kernel(const WgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char wg3_lds[];
-  char* Ys = wg3_lds;                  // hi image, lo image of the dY tile
-  char* Xs = wg3_lds + 2 * W3_IMG;     // hi image, lo image of the X tile
+__global__ __launch_bounds__(WG_THREADS, 4) void ws6_wgrad_kernel(const WgArgs a) {
+  __shared__ __attribute__((aligned(16))) char Ys[3 * W6_IMG];   // hi, mid, lo images of the dY tile
+  __shared__ __attribute__((aligned(16))) char Xs[3 * W6_IMG];   // hi, mid, lo images of the X tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, ci = lane & 15;
   const int wm = wave >> 2, wn = wave & 3;           // this wave: rows 64 wm .. +63 of dW, columns 32 wn .. +31
-  const int P = a.P, tpp = (P + WG_TP - 1) / WG_TP, ntiles = a.B * tpp;
-  const unsigned o0 = (unsigned)(tid >> 4) * P + 4 * (tid & 15);
-  const int oc = 4 * (tid & 15);
+  const int P = a.P, tpp = (P + W6_TP - 1) / W6_TP, ntiles = a.B * tpp;
+  const unsigned o0 = (unsigned)(tid >> 3) * P + 4 * (tid & 7);
+  const int oc = 4 * (tid & 7);
   const int nloc = ((int)ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid never exceeds the tile count
 
   floatx4 acc[4][2];
@@ -180,25 +186,25 @@ __global__ __launch_bounds__(WG_THREADS, 4) void ws3_wgrad_kernel(const WgArgs a
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-  float dbv[4] = {0.f, 0.f, 0.f, 0.f};               // row sums of dY for rows (tid >> 4) + 32 v
+  float dbv[2] = {0.f, 0.f};                         // row sums of dY for rows (tid >> 3) + 64 v
 
-  Wg3Pre py, px;
+  Wg6Pre py, px;
   bool pin = false;
   // unconditional, clamped loads (counted waits stay exact, see dppm_wsplit.h); tiles past the end re-read the last one
   auto issue = [&](int i) {
     const int t = (int)blockIdx.x + (i < nloc ? i : nloc - 1) * (int)gridDim.x;
-    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WG_TP);
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * W6_TP);
     pin = p0 + oc < P;
     const unsigned o = pin ? o0 : 0u;
-    wg3_issue(py, a.dY + (size_t)b * a.dy_bs + p0, P, o);
-    wg3_issue(px, a.X + (size_t)b * a.x_bs + p0, P, o);
+    wg6_issue(py, a.dY + (size_t)b * a.dy_bs + p0, P, o);
+    wg6_issue(px, a.X + (size_t)b * a.x_bs + p0, P, o);
   };
   auto land = [&]() {
-    wg3_land(py, Ys, tid, pin);
-    wg3_land(px, Xs, tid, pin);
+    wg6_land(py, Ys, tid, pin);
+    wg6_land(px, Xs, tid, pin);
     if (WITH_DB && pin) {
-      dbv[0] += (py.a.x + py.a.y) + (py.a.z + py.a.w); dbv[1] += (py.b.x + py.b.y) + (py.b.z + py.b.w);
-      dbv[2] += (py.c.x + py.c.y) + (py.c.z + py.c.w); dbv[3] += (py.d.x + py.d.y) + (py.d.z + py.d.w);
+      dbv[0] += (py.a.x + py.a.y) + (py.a.z + py.a.w);
+      dbv[1] += (py.b.x + py.b.y) + (py.b.z + py.b.w);
     }
   };
   issue(0);
@@ -207,26 +213,28 @@ __global__ __launch_bounds__(WG_THREADS, 4) void ws3_wgrad_kernel(const WgArgs a
   for (int i = 0; i < nloc; ++i) {
     const bool more = i + 1 < nloc;
     issue(i + 1);
+    uintx4 bh[2], bm[2], bl[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uintx4 bh[2], bl[2];
+    for (int j = 0; j < 2; ++j) {
+      const unsigned bo = wg6_off(32 * wn + 16 * j + ci, g);
+      bh[j] = *reinterpret_cast<const uintx4*>(Xs + bo);
+      bm[j] = *reinterpret_cast<const uintx4*>(Xs + W6_IMG + bo);
+      bl[j] = *reinterpret_cast<const uintx4*>(Xs + 2 * W6_IMG + bo);
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned bo = wg3_off(32 * wn + 16 * j + ci, 4 * ks + g);
-        bh[j] = *reinterpret_cast<const uintx4*>(Xs + bo);
-        bl[j] = *reinterpret_cast<const uintx4*>(Xs + W3_IMG + bo);
-      }
+    for (int ii = 0; ii < 4; ++ii) {
+      const unsigned ao = wg6_off(64 * wm + 16 * ii + ci, g);
+      const uintx4 ah = *reinterpret_cast<const uintx4*>(Ys + ao);
+      const uintx4 am = *reinterpret_cast<const uintx4*>(Ys + W6_IMG + ao);
+      const uintx4 al = *reinterpret_cast<const uintx4*>(Ys + 2 * W6_IMG + ao);
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        const unsigned ao = wg3_off(64 * wm + 16 * ii + ci, 4 * ks + g);
-        const uintx4 ah = *reinterpret_cast<const uintx4*>(Ys + ao);
-        const uintx4 al = *reinterpret_cast<const uintx4*>(Ys + W3_IMG + ao);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[ii][j] = w3_mfma(al, bh[j], acc[ii][j]);
-          acc[ii][j] = w3_mfma(ah, bl[j], acc[ii][j]);
-          acc[ii][j] = w3_mfma(ah, bh[j], acc[ii][j]);
-        }
+      for (int j = 0; j < 2; ++j) {   // smallest terms first
+        acc[ii][j] = w3_mfma(am, bm[j], acc[ii][j]);
+        acc[ii][j] = w3_mfma(al, bh[j], acc[ii][j]);
+        acc[ii][j] = w3_mfma(ah, bl[j], acc[ii][j]);
+        acc[ii][j] = w3_mfma(am, bh[j], acc[ii][j]);
+        acc[ii][j] = w3_mfma(ah, bm[j], acc[ii][j]);
+        acc[ii][j] = w3_mfma(ah, bh[j], acc[ii][j]);
       }
     }
     __syncthreads();
@@ -244,25 +252,12 @@ __global__ __launch_bounds__(WG_THREADS, 4) void ws3_wgrad_kernel(const WgArgs a
       for (int r = 0; r < 4; ++r) slab[(64 * wm + 16 * i + 4 * g + r) * WS_H + 32 * wn + 16 * j + ci] = acc[i][j][r];
   if (WITH_DB) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 2; ++v) {
       float s = dbv[v];
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-      if ((tid & 15) == 0) slab[WS_H * WS_H + (tid >> 4) + 32 * v] = s;
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if ((tid & 7) == 0) slab[WS_H * WS_H + (tid >> 3) + 64 * v] = s;
     }
   }
-}
-
-template <bool WITH_DB>
-inline int ws3_wgrad_launch(const WgArgs& a, int grid, hipStream_t st) {
-  static bool set = false;
-  const size_t lds = 4 * (size_t)W3_IMG;
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ws3_wgrad_kernel<WITH_DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "ws3_wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set = true;
-  }
-  hipLaunchKernelGGL(ws3_wgrad_kernel<WITH_DB>, dim3(grid), dim3(WG_THREADS), lds, st, a);
-  return check_launch("ws3_wgrad");
 }
 
 // stage 1: part[zc][e] = sum of slabs zc * per .. (zc + 1) * per - 1 ; stage 2: out = sum_zc part[zc][e]   (fixed orders)
@@ -293,17 +288,16 @@ inline int ws_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int 
   if (!dY || !X || !dW || !scratch || B <= 0 || P <= 0 || P % 4 != 0) return fail(DPPM_E_INVALID, "ws_wgrad: bad arguments");
   if (!ws_al16(dY) || !ws_al16(X) || dy_bs % 4 != 0 || x_bs % 4 != 0) return fail(DPPM_E_INVALID, "ws_wgrad: planes must be 16-byte aligned");
   if ((long)WS_H * P >= (1L << 31)) return fail(DPPM_E_INVALID, "ws_wgrad: P=%d too large", P);
-  const long ntiles = (long)B * ((P + WG_TP - 1) / WG_TP);
+  const long ntiles = (long)B * ((P + (split ? W6_TP : WG_TP) - 1) / (split ? W6_TP : WG_TP));
   const int grid = (int)(ntiles < WG_GRID ? ntiles : WG_GRID);
   WgArgs a{dY, dy_bs, X, x_bs, scratch, B, P};
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  int rc = DPPM_OK;
-  if (split) rc = db ? ws3_wgrad_launch<true>(a, grid, st) : ws3_wgrad_launch<false>(a, grid, st);
+  if (split && db) hipLaunchKernelGGL(ws6_wgrad_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, st, a);
+  else if (split) hipLaunchKernelGGL(ws6_wgrad_kernel<false>, dim3(grid), dim3(WG_THREADS), 0, st, a);
   else if (db) hipLaunchKernelGGL(ws_wgrad_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, st, a);
   else hipLaunchKernelGGL(ws_wgrad_kernel<false>, dim3(grid), dim3(WG_THREADS), 0, st, a);
   if (prof) prof_after(st, PROF_WGRAD, 2.0 * WS_H * WS_H * (double)P * B);
-  DPPM_TRY(rc);
   DPPM_TRY(check_launch("ws_wgrad"));
   const int ne = db ? WG_SLAB : WS_H * WS_H;
   const int per = (grid + WG_ZC - 1) / WG_ZC, nzc = (grid + per - 1) / per;

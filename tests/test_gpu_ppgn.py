@@ -344,9 +344,10 @@ def test_adam_matches_torch(ops):
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-7)
 
 
-def test_split_wgrad_opt_in():
-    """DPPM_WGRAD_BF16X3=1 (read once per process, hence the child process): weight gradients with split-bf16 products stay within
-    1e-3 of the exact-float32 kernels' on a well-conditioned H = 128 network."""
+def test_split_wgrad_vs_exact():
+    """The default weight-gradient kernel (three-piece bf16 split, six MFMAs per product) against the exact-float32 MFMA kernel
+    (DPPM_WGRAD_F32=1, read once per process, hence the child processes): float32-grade agreement, 2e-5 of each weight tensor's
+    scale; the bias gradients are plain float32 row sums in both kernels and differ by summation order only (2e-4)."""
     import subprocess
     import sys
     code = r'''
@@ -364,7 +365,7 @@ np.savez(sys.argv[1], **g)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     outs = []
-    for env in ({}, {"DPPM_WGRAD_BF16X3": "1"}):
+    for env in ({"DPPM_WGRAD_F32": "1"}, {}):
         with tempfile.NamedTemporaryFile(suffix=".npz") as f:
             subprocess.check_call([sys.executable, "-c", code, f.name], env={**os.environ, **env})
             outs.append(dict(np.load(f.name)))
@@ -373,6 +374,8 @@ np.savez(sys.argv[1], **g)
     for k in outs[0]:
         scale = max(np.abs(outs[0][k]).max(), 2e-2 * gmax)
         err = np.abs(outs[0][k] - outs[1][k]).max()
-        assert err <= 1e-3 * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
+        tol = 2e-5 if outs[0][k].ndim >= 2 else 2e-4
+        print(f"{k}: {err / scale:.2e}")
+        assert err <= tol * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
         differs |= err > 0
     assert differs       # the switch did select the other kernel
