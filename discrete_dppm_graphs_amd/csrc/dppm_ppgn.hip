@@ -259,6 +259,33 @@ __global__ __launch_bounds__(256) void diag_set_kernel(float* __restrict__ plane
   for (int i = threadIdx.x; i < N; i += blockDim.x) plane[(size_t)b * bs + (size_t)i * ld + i] = v;
 }
 
+// d layer_cond[b] = sum_i dX[b][pad channel][i][i]: the conditioning scalar sits on that channel's diagonal (diag_set_kernel)
+__global__ __launch_bounds__(64) void diag_sum_kernel(const float* __restrict__ plane, long bs, int N, int ld, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N; i += 64) s += plane[(size_t)b * bs + (size_t)i * ld + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[b] = s;
+}
+
+// d sigma[b]: sigma sits on the diagonal of input channel 1 (prep_kernel), which feeds in_lin (gradient du0) and the readout
+// layer_cat_lin (gradient dR):  sum_i sum_c ( in_w[c][1] du0[b][c][ii] + cat_w[c][1] dR[b][c][ii] )
+__global__ __launch_bounds__(256) void dsigma_kernel(const float* __restrict__ du0, const float* __restrict__ dR, const float* __restrict__ in_w,
+                                                     const float* __restrict__ cat_w, int CT, int H, int N, int ld, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const size_t P = (size_t)N * ld;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < H * N; e += 256) {
+    const int c = e / N, i = e % N;
+    const size_t at = ((size_t)b * H + c) * P + (size_t)i * ld + i;
+    s += in_w[2 * c + 1] * du0[at] + cat_w[(size_t)c * CT + 1] * dR[at];
+  }
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) out[b] = s;
+}
+
 // logits[b][i][j] = sum_o wfin[o] * (R + act)[b][o][p] + bfin     (model/ppgn.py:331-333; dropout is identity in eval)
 __global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict__ R, const float* __restrict__ act,
                                                         const float* __restrict__ wfin, const float* __restrict__ bfin,
@@ -679,8 +706,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
   DPPM_REQUIRE(dlogits && workspace, "dppm_ppgn_backward: null pointer");
   DPPM_REQUIRE(B > 0 && N > 0, "dppm_ppgn_backward: B=%d N=%d must be positive", B, N);
   DPPM_REQUIRE(gr->hidden == pr->hidden && gr->num_layers == pr->num_layers, "dppm_ppgn_backward: grads/params shape mismatch");
-  if (dsigma) return fail(DPPM_E_UNSUPPORTED, "dppm_ppgn_backward: dsigma is not implemented yet");
-  if (pr->layer_cond) return fail(DPPM_E_UNSUPPORTED, "dppm_ppgn_backward: layer_cond (Powerful_Ind conditioning) is inference-only");
+  DPPM_REQUIRE(!pr->layer_cond || gr->layer_cond, "dppm_ppgn_backward: params carry layer_cond, grads->layer_cond ([L][B]) must receive its gradient");
   const int H = pr->hidden, L = pr->num_layers;
   Ctx c{as_stream(stream), make_layout(B, N, H, L, 1), static_cast<float*>(workspace)};
   const Layout& w = c.w;
@@ -798,8 +824,16 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       DPPM_TRY(wgrad(c, H, dpre, hs, H, x, x_bs, gw0[k], H, gb0[k]));
       if (!ws) DPPM_TRY(linear(c, H, LinArgs{wl0[k], H, true, dpre, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, true));
     }
+    if (pr->layer_cond) {   // dx is complete here: readout, m4 skip and both MLPs have been added
+      hipLaunchKernelGGL(diag_sum_kernel, dim3(B), dim3(64), 0, c.st, (const float*)(dx + (size_t)(H - 1) * P), dx_bs, N, w.ld, const_cast<float*>(gr->layer_cond) + (size_t)l * B);
+      DPPM_TRY(check_launch("diag_sum"));
+    }
   }
   // in_lin
   DPPM_TRY(wgrad(c, H, du0, hs, 2, cat, cat_bs, gr->in_w, 2, gr->in_b));
+  if (dsigma) {   // dh still holds dR (nothing after the head reuses it)
+    hipLaunchKernelGGL(dsigma_kernel, dim3(B), dim3(256), 0, c.st, (const float*)du0, (const float*)dh, pr->in_w, pr->cat_w, w.CT, H, N, w.ld, dsigma);
+    DPPM_TRY(check_launch("dsigma"));
+  }
   return DPPM_OK;
 }

@@ -46,15 +46,16 @@ def schedule_vlb(noise_num):
 
 # ---------------------------------------------------------------------------------------------- flat parameters
 class FlatState:
-    """Used parameters of a `Powerful` re-homed into one contiguous float32 buffer (each nn.Parameter becomes a view,
+    """Trained parameters of a `Powerful` (or a conditioning variant) re-homed into one contiguous float32 buffer (each nn.Parameter becomes a view,
     names and shapes unchanged), plus a flat gradient bucket and Adam moments.  Unused parameters (time_mlp,
     feature_extractors) never receive gradients in the reference either and are left alone, exactly as
     torch.optim.Adam skips parameters whose .grad is None."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.model = model
-        self.names = model.used_param_names()
-        params = model._used_params()
+        self.names = model.trainable_param_names()
+        named = dict(model.named_parameters())
+        params = [named[n] for n in self.names]
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatState: move the model to the GPU first (no CPU fallback)")
@@ -72,7 +73,7 @@ class FlatState:
             p.data = view
             grads[name] = self.grad[off:off + p.numel()].view_as(p)
         self.grad_views = grads
-        self.grad_pack = ops.ParamPack(grads, model.num_layers, model.hidden)
+        self.grad_pack = model.make_grad_pack(grads)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         model._pack_cache = None
@@ -117,8 +118,9 @@ class FlatState:
 
     def publish_grads(self):
         """Expose the flat bucket as .grad on the parameters (for callers that want to inspect or clip)."""
-        for name, p in zip(self.names, self.model._used_params()):
-            p.grad = self.grad_views[name]
+        named = dict(self.model.named_parameters())
+        for name in self.names:
+            named[name].grad = self.grad_views[name]
 
 
 # ---------------------------------------------------------------------------------------------- training steps

@@ -97,6 +97,57 @@ class _PowerfulFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads[n] for n in names)
 
 
+class _PackedFn(torch.autograd.Function):
+    """autograd bridge over explicit kernel-layout tensors (ops.used_param_names order) that are themselves results of
+    differentiable torch ops on a module's parameters (zero padding, effective biases), plus d/d sigma and d/d layer_cond.
+    Every training forward owns its workspace (several forwards may precede one backward)."""
+
+    @staticmethod
+    def forward(ctx, L, H, A, mask, sigma, layer_cond, *tensors):
+        names = ops.used_param_names(L)
+        tens = {n: t.detach().contiguous() for n, t in zip(names, tensors)}
+        cond = layer_cond.detach().contiguous() if layer_cond is not None else None
+        pack = ops.ParamPack(tens, L, H, layer_cond=cond)
+        B, N, _ = A.shape
+        ws = ops.ppgn_workspace(B, N, H, L, True, A.device)
+        sig = sigma.detach().contiguous()
+        logits = ops.ppgn_forward(pack, A, mask, sig, ws, training=True)
+        ctx.pack, ctx.ws, ctx.geom, ctx.names = pack, ws, (L, H), names
+        ctx.save_for_backward(A, mask, sig)
+        return logits
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dlogits):
+        A, mask, sig = ctx.saved_tensors
+        L, H = ctx.geom
+        pack = ctx.pack
+        grads = {n: torch.empty_like(pack.tensors[n]) for n in ctx.names}
+        dcond = torch.empty_like(pack.layer_cond) if pack.layer_cond is not None else None
+        dsig = torch.empty_like(sig) if ctx.needs_input_grad[4] else None
+        ops.ppgn_backward(pack, ops.ParamPack(grads, L, H, layer_cond=dcond), A, mask, sig, dlogits.contiguous(), ctx.ws, dsigma=dsig)
+        ctx.ws = ctx.pack = None
+        return (None, None, None, None, dsig, dcond) + tuple(grads[n] for n in ctx.names)
+
+
+def autograd_forward_backward(model, A, mask, noiselevel, loss_grad_fn, grad_views):
+    """forward + loss gradient + backward for the engine (engine.FlatState) when part of the model is ordinary torch code
+    (learned noise embeddings, padded / effective parameter tensors): the graph is model._train_logits, the parameter
+    gradients are copied into `grad_views` ({name: view of the flat gradient bucket})."""
+    with torch.enable_grad():
+        logits = model._train_logits(A, mask, noiselevel)
+    loss, dlogits = loss_grad_fn(logits.detach())
+    names = list(grad_views)
+    sd = dict(model.named_parameters())
+    gs = torch.autograd.grad(logits, [sd[n] for n in names], dlogits, allow_unused=True)
+    for n, g in zip(names, gs):
+        if g is None:
+            grad_views[n].zero_()
+        else:
+            grad_views[n].copy_(g)
+    return loss, logits.detach()
+
+
 class Powerful(nn.Module):
     def __init__(self, use_norm_layers=False, name="ppgn", channel_num_list=None, feature_nums=None,
                  gnn_hidden_num_list=None, num_layers=6, input_features=2, hidden=32, hidden_final=32,
@@ -156,7 +207,10 @@ class Powerful(nn.Module):
         params = self._used_params()
         # grad mode is off inside Function.forward, so the decision to keep the backward workspace is taken here
         training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        logits = _PowerfulFn.apply(self, training, A, mask, sigma, *params)
+        if training and sigma.requires_grad:   # learned noise_mlp: d logits / d sigma flows back into time_mlp
+            logits = _PackedFn.apply(self.num_layers, self.hidden, A, mask, sigma, None, *params)
+        else:
+            logits = _PowerfulFn.apply(self, training, A, mask, sigma, *params)
         return logits.unsqueeze(-1)
 
     # ------------------------------------------------------------------ engine surface (no autograd)
@@ -164,6 +218,8 @@ class Powerful(nn.Module):
     def forward_backward(self, A, mask, noiselevel, loss_grad_fn, grad_pack):
         """logits = f(A); (loss, dlogits) = loss_grad_fn(logits); parameter gradients are written through `grad_pack`
         (an ops.ParamPack over caller-owned buffers, e.g. views of one flat gradient bucket).  Returns (loss, logits)."""
+        if isinstance(grad_pack, dict):   # learned noise_mlp: time_mlp is torch code in front of the kernels
+            return autograd_forward_backward(self, A, mask, noiselevel, loss_grad_fn, grad_pack)
         A, mask, sigma = self._prepare(A, mask, noiselevel)
         B, N, _ = A.shape
         ws = self._workspace(B, N, True, A.device, cached=True)
@@ -183,7 +239,21 @@ class Powerful(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def used_param_names(self):
+        """Names the kernels read, in C-ABI order."""
         return ops.used_param_names(self.num_layers)
+
+    def trainable_param_names(self):
+        """What an optimiser updates: the kernels' parameters, plus time_mlp when it produces sigma (model/ppgn.py:273-274)."""
+        extra = [f"time_mlp.{i}.{k}" for i in (0, 2) for k in ("weight", "bias")] if self.noise_mlp else []
+        return self.used_param_names() + extra
+
+    def make_grad_pack(self, grad_views):
+        """The object forward_backward writes gradients through: a C-ABI pointer pack, or the views themselves when autograd is
+        in the loop."""
+        return dict(grad_views) if self.noise_mlp else ops.ParamPack(grad_views, self.num_layers, self.hidden)
+
+    def _train_logits(self, A, mask, noiselevel):
+        return self.forward_cat(A, None, mask, noiselevel)[..., 0]
 
     def _used_params(self):
         sd = dict(self.named_parameters())
@@ -251,12 +321,8 @@ class Powerful(nn.Module):
         if sigma.numel() != B:
             raise ValueError(f"noiselevel: {sigma.numel()} values for {B} graphs")
         sigma = sigma.contiguous()
-        if self.noise_mlp:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.time_mlp.parameters()):
-                raise NotImplementedError("noise_mlp=True is inference-only in this build (d logits / d sigma is not "
-                                          "exported yet); every shipped config sets noise_mlp: false")
-            with torch.no_grad():
-                sigma = self.time_mlp(sigma.view(B, 1)).view(B).contiguous()   # model/ppgn.py:273-274
+        if self.noise_mlp:   # model/ppgn.py:273-274; under autograd the result keeps its graph (dsigma comes back from the C-ABI)
+            sigma = self.time_mlp(sigma.view(B, 1)).view(B).contiguous()
         if self.training and self.dropout_p > 1e-4:
             raise NotImplementedError(f"dropout_p={self.dropout_p}: only the reference's p=1e-6 (treated as identity) is supported")
         return A, mask, sigma

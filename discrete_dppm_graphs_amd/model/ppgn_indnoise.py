@@ -15,8 +15,10 @@ How they map onto the H-channel kernels of libdppm_hip.so
 The embedding MLPs act on one scalar per call (O(hidden^2) work); they run as torch ops on the GPU.  Everything per position
 runs in the HIP kernels; there is no fallback.
 
-Inference only in this build: the C-ABI exports no gradient with respect to the conditioning scalars, so a forward with
-autograd enabled on trainable parameters raises NotImplementedError (no shipped config selects these models).
+Training: under autograd the kernel-layout tensors (padded matrices / effective biases) are built from the parameters with
+differentiable torch ops and handed to ppgn._PackedFn, whose backward is one dppm_ppgn_backward call that also returns
+d/d layer_cond and d/d sigma; torch carries those on into the embedding layers.  The engine (engine.FlatState / fit) reaches
+the same path through forward_backward.  Powerful_sincos with different noise levels inside one batch runs graph by graph.
 """
 import math
 
@@ -26,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .ppgn import SLOPE, FeatureExtractor, PowerfulLayer, _Seq, default_precision
+from .ppgn import SLOPE, FeatureExtractor, PowerfulLayer, _PackedFn, _Seq, autograd_forward_backward, default_precision
 
 
 class _VariantBase(nn.Module):
@@ -76,9 +78,33 @@ class _VariantBase(nn.Module):
     def forward_cat(self, A, node_features, mask, noiselevel):
         del node_features
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(f"{type(self).__name__} is inference-only in this build (wrap the call in torch.no_grad()); "
-                                      "training these conditioning variants is not provided")
+            return self._train_logits(A, mask, noiselevel).unsqueeze(-1)
         return self.infer(A, mask, noiselevel).unsqueeze(-1)
+
+    # ------------------------------------------------------------------ engine surface (engine.FlatState, fit)
+    def _kernel_param_names(self):
+        names = ["in_lin.0.weight", "in_lin.0.bias"]
+        for l in range(self.num_layers):
+            names += [f"convs.{l}.{m}.{k}.{w}" for m in ("m1", "m2") for k in ("0", "2") for w in ("weight", "bias")]
+            names += [f"convs.{l}.m4.0.weight", f"convs.{l}.m4.0.bias"]
+        return names + [f"{m}.0.{w}" for m in ("layer_cat_lin", "after_conv", "final_lin") for w in ("weight", "bias")]
+
+    def used_param_names(self):
+        return self.trainable_param_names()
+
+    def _used_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in self.trainable_param_names()]
+
+    def make_grad_pack(self, grad_views):
+        return dict(grad_views)
+
+    def forward_backward(self, A, mask, noiselevel, loss_grad_fn, grad_pack):
+        return autograd_forward_backward(self, A, mask, noiselevel, loss_grad_fn, grad_pack)
+
+    def _check_dropout(self):
+        if self.training and self.dropout_p > 1e-4:
+            raise NotImplementedError(f"dropout_p={self.dropout_p}: only the reference's p=1e-6 (treated as identity) is supported")
 
     # ------------------------------------------------------------------ helpers
     def _inputs(self, A, mask, noiselevel):
@@ -148,61 +174,75 @@ class Powerful_Ind(_VariantBase):
         self.after_conv = _Seq(nn.Linear(hidden_final - 1, hidden_final - 1))
         self.final_lin = _Seq(nn.Linear(hidden_final - 1, output_features))
 
-    def _padded_pack(self):
-        """The (hidden-1)-wide matrices zero-padded to `hidden` (module docstring), rebuilt when a parameter changes."""
-        sig = self._signature()
-        if self._pad_cache is not None and self._pad_cache[0] == sig:
-            return self._pad_cache[1]
+    def trainable_param_names(self):
+        names = self._kernel_param_names() + [f"times.{l + 1}.0.{w}" for l in range(self.num_layers) for w in ("weight", "bias")]
+        if self.noise_mlp:
+            names += [f"time_mlp.{i}.{w}" for i in (0, 2) for w in ("weight", "bias")] + ["times.0.0.weight", "times.0.0.bias"]
+        return names
+
+    def _padded_tensors(self, sd):
+        """The (hidden-1)-wide matrices zero-padded to `hidden` (module docstring), by differentiable ops on `sd`'s tensors."""
         H, h, L = self.hidden, self.hidden - 1, self.num_layers
-        sd = {k: v.detach() for k, v in self.named_parameters()}
-        t = {}
 
-        def pad(name, rows, cols=None):
-            src = sd[name]
-            dst = self._zeros(rows) if cols is None else self._zeros(rows, cols)
+        def pad(src, rows, cols=None):
             if cols is None:
-                dst[:src.shape[0]] = src
-            else:
-                dst[:src.shape[0], :src.shape[1]] = src
-            return dst
+                return F.pad(src, (0, rows - src.shape[0]))
+            return F.pad(src, (0, cols - src.shape[1], 0, rows - src.shape[0]))
 
-        t["in_lin.0.weight"], t["in_lin.0.bias"] = pad("in_lin.0.weight", H, 2), pad("in_lin.0.bias", H)
+        t = {"in_lin.0.weight": pad(sd["in_lin.0.weight"], H, 2), "in_lin.0.bias": pad(sd["in_lin.0.bias"], H)}
         for l in range(L):
             for m in ("m1", "m2"):
                 for k in ("0", "2"):
-                    t[f"convs.{l}.{m}.{k}.weight"] = pad(f"convs.{l}.{m}.{k}.weight", H, H)
-                    t[f"convs.{l}.{m}.{k}.bias"] = pad(f"convs.{l}.{m}.{k}.bias", H)
+                    t[f"convs.{l}.{m}.{k}.weight"] = pad(sd[f"convs.{l}.{m}.{k}.weight"], H, H)
+                    t[f"convs.{l}.{m}.{k}.bias"] = pad(sd[f"convs.{l}.{m}.{k}.bias"], H)
             w4 = sd[f"convs.{l}.m4.0.weight"]            # [h, h + H]: cat(contraction (h channels), layer input (H channels))
-            p4 = self._zeros(H, 2 * H)
-            p4[:h, :h] = w4[:, :h]
-            p4[:h, H:] = w4[:, h:]
-            t[f"convs.{l}.m4.0.weight"], t[f"convs.{l}.m4.0.bias"] = p4, pad(f"convs.{l}.m4.0.bias", H)
+            t[f"convs.{l}.m4.0.weight"] = torch.cat([pad(w4[:, :h], H, H), pad(w4[:, h:], H, H)], dim=1)
+            t[f"convs.{l}.m4.0.bias"] = pad(sd[f"convs.{l}.m4.0.bias"], H)
         wc = sd["layer_cat_lin.0.weight"]                # [h, 2 + L h]
-        pc = self._zeros(H, 2 + L * H)
-        pc[:h, :2] = wc[:, :2]
-        for l in range(L):
-            pc[:h, 2 + l * H:2 + l * H + h] = wc[:, 2 + l * h:2 + (l + 1) * h]
-        t["layer_cat_lin.0.weight"], t["layer_cat_lin.0.bias"] = pc, pad("layer_cat_lin.0.bias", H)
-        t["after_conv.0.weight"], t["after_conv.0.bias"] = pad("after_conv.0.weight", H, H), pad("after_conv.0.bias", H)
-        t["final_lin.0.weight"], t["final_lin.0.bias"] = pad("final_lin.0.weight", 1, H), sd["final_lin.0.bias"].clone()
-        pack = ops.ParamPack(t, L, H)
+        t["layer_cat_lin.0.weight"] = torch.cat([pad(wc[:, :2], H, 2)] + [pad(wc[:, 2 + l * h:2 + (l + 1) * h], H, H) for l in range(L)], dim=1)
+        t["layer_cat_lin.0.bias"] = pad(sd["layer_cat_lin.0.bias"], H)
+        t["after_conv.0.weight"], t["after_conv.0.bias"] = pad(sd["after_conv.0.weight"], H, H), pad(sd["after_conv.0.bias"], H)
+        t["final_lin.0.weight"], t["final_lin.0.bias"] = pad(sd["final_lin.0.weight"], 1, H), sd["final_lin.0.bias"]
+        return t
+
+    def _padded_pack(self):
+        """Inference pack over the padded tensors, rebuilt when a parameter changes."""
+        sig = self._signature()
+        if self._pad_cache is not None and self._pad_cache[0] == sig:
+            return self._pad_cache[1]
+        with torch.no_grad():
+            t = {k: v.contiguous() for k, v in self._padded_tensors({k: v.detach() for k, v in self.named_parameters()}).items()}
+        pack = ops.ParamPack(t, self.num_layers, self.hidden)
         self._pad_cache = (sig, pack)
         return pack
+
+    def _conditioning(self, sigma):
+        """(sigma-channel input [B], layer_cond [L, B]) as ppgn_indnoise.py:279-287,306-315 compute them."""
+        B = sigma.numel()
+        cond = sigma.view(B, 1)
+        if self.noise_mlp:
+            cond = self.time_mlp(cond)
+            nin = self.times[0](cond)
+        else:
+            nin = cond
+        layer_cond = torch.cat([self.times[l + 1](cond) for l in range(self.num_layers)], dim=1).t().contiguous()
+        return nin.reshape(B), layer_cond
+
+    def _train_logits(self, A, mask, noiselevel):
+        self._check_dropout()
+        A, mask, sigma = self._inputs(A, mask, noiselevel)
+        nin, layer_cond = self._conditioning(sigma)
+        t = self._padded_tensors(dict(self.named_parameters()))
+        return _PackedFn.apply(self.num_layers, self.hidden, A, mask, nin, layer_cond, *[t[n] for n in ops.used_param_names(self.num_layers)])
 
     @torch.no_grad()
     def infer(self, A, mask, noiselevel, out=None):
         A, mask, sigma = self._inputs(A, mask, noiselevel)
         B, N, _ = A.shape
-        cond = sigma.view(B, 1)
-        if self.noise_mlp:      # ppgn_indnoise.py:279-287
-            cond = self.time_mlp(cond)
-            nin = self.times[0](cond)
-        else:
-            nin = cond
-        layer_cond = torch.cat([self.times[l + 1](cond) for l in range(self.num_layers)], dim=1).t().contiguous()   # [L, B]
+        nin, layer_cond = self._conditioning(sigma)
         pack = self._padded_pack()
         pack.set_layer_cond(layer_cond)
-        return ops.ppgn_forward(pack, A, mask, nin.reshape(B).contiguous(), self._workspace(B, N, A.device), training=False, out=out,
+        return ops.ppgn_forward(pack, A, mask, nin.contiguous(), self._workspace(B, N, A.device), training=False, out=out,
                                 precision=self.precision)
 
 
@@ -279,6 +319,55 @@ class Powerful_sincos(_VariantBase):
         pack = ops.ParamPack(t, L, H)
         self._pad_cache = (sig, pack, eff)
         return pack, eff
+
+    def trainable_param_names(self):
+        names = self._kernel_param_names() + [f"time_mlp.{i}.{w}" for i in (1, 3) for w in ("weight", "bias")]
+        return names + [f"times.{l}.0.{w}" for l in range(self.num_layers + 1) for w in ("weight", "bias")]
+
+    def _eff_tensors(self, sd, sigma1):
+        """Kernel-layout tensors for ONE noise level by differentiable ops: the embeddings folded into the first-Linear biases."""
+        H, L = self.hidden, self.num_layers
+        pre = self.time_mlp(sigma1)                                       # [1, H]
+        e0 = F.leaky_relu(self.times[0](pre), SLOPE).reshape(())          # scalar added to A before in_lin
+        zcol = torch.zeros(H, 1, device=pre.device, dtype=pre.dtype)
+        w_in, wc = sd["in_lin.0.weight"], sd["layer_cat_lin.0.weight"]
+        t = {"in_lin.0.weight": torch.cat([w_in[:, :1], zcol], dim=1), "in_lin.0.bias": sd["in_lin.0.bias"] + w_in[:, 0] * e0,
+             "layer_cat_lin.0.weight": torch.cat([wc[:, :1], zcol, wc[:, 1:]], dim=1),
+             "layer_cat_lin.0.bias": sd["layer_cat_lin.0.bias"] + wc[:, 0] * e0}
+        for l in range(L):
+            e = F.leaky_relu(self.times[l + 1](pre), SLOPE).reshape(H)    # added to every channel before layer l
+            for m in ("m1", "m2"):
+                t[f"convs.{l}.{m}.0.weight"] = sd[f"convs.{l}.{m}.0.weight"]
+                t[f"convs.{l}.{m}.0.bias"] = torch.addmv(sd[f"convs.{l}.{m}.0.bias"], sd[f"convs.{l}.{m}.0.weight"], e)
+                t[f"convs.{l}.{m}.2.weight"], t[f"convs.{l}.{m}.2.bias"] = sd[f"convs.{l}.{m}.2.weight"], sd[f"convs.{l}.{m}.2.bias"]
+            w4 = sd[f"convs.{l}.m4.0.weight"]
+            t[f"convs.{l}.m4.0.weight"] = w4
+            t[f"convs.{l}.m4.0.bias"] = torch.addmv(sd[f"convs.{l}.m4.0.bias"], w4[:, H:], e)
+        for n in ("after_conv.0.weight", "after_conv.0.bias", "final_lin.0.weight", "final_lin.0.bias"):
+            t[n] = sd[n]
+        return t
+
+    def _train_logits(self, A, mask, noiselevel):
+        if not self.noise_mlp:
+            raise RuntimeError("Powerful_sincos needs noise_mlp=True (model/ppgn_indnoise_sincos.py:198-203)")
+        self._check_dropout()
+        A, mask, sigma = self._inputs(A, mask, noiselevel)
+        B = A.shape[0]
+        sd = dict(self.named_parameters())
+        names = ops.used_param_names(self.num_layers)
+        # one effective-bias set per distinct noise level: consecutive graphs that share sigma run as one call
+        host = sigma.tolist()
+        outs, b0 = [], 0
+        while b0 < B:
+            b1 = b0 + 1
+            while b1 < B and host[b1] == host[b0]:
+                b1 += 1
+            t = self._eff_tensors(sd, sigma[b0:b0 + 1])
+            zero_sigma = torch.zeros(b1 - b0, device=A.device, dtype=torch.float32)
+            outs.append(_PackedFn.apply(self.num_layers, self.hidden, A[b0:b1].contiguous(), mask[b0:b1].contiguous(), zero_sigma, None,
+                                        *[t[n] for n in names]))
+            b0 = b1
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     @torch.no_grad()
     def infer(self, A, mask, noiselevel, out=None):

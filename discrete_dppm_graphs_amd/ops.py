@@ -247,12 +247,18 @@ def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None, prec
     return logits
 
 
-def ppgn_backward(pack, grad_pack, A, mask, sigma, dlogits, workspace):
+def ppgn_backward(pack, grad_pack, A, mask, sigma, dlogits, workspace, dsigma=None):
+    """Parameter gradients through `grad_pack`; dsigma ([B], optional) receives d/d sigma; when `pack` carries layer_cond,
+    `grad_pack.layer_cond` ([L, B]) receives its gradient."""
     A = _chk(A, "A")
     B, N, _ = A.shape
     dlogits = _chk(dlogits, "dlogits", (B, N, N))
+    if dsigma is not None:
+        _chk(dsigma, "dsigma", (B,))
+    if pack.layer_cond is not None and (grad_pack.layer_cond is None or grad_pack.layer_cond.shape != pack.layer_cond.shape):
+        raise ValueError("ppgn_backward: grad_pack needs a layer_cond buffer of the parameters' layer_cond shape")
     check(lib.dppm_ppgn_backward(pack.ref(), grad_pack.ref(), _ptr(A), _ptr(mask), _ptr(sigma), B, N, _ptr(dlogits),
-                                 C.c_void_p(0), _ptr(workspace), C.c_size_t(workspace.numel() * 4), _stream()),
+                                 _ptr(dsigma), _ptr(workspace), C.c_size_t(workspace.numel() * 4), _stream()),
           "dppm_ppgn_backward")
 
 

@@ -141,7 +141,9 @@ typedef struct dppm_ppgn_params {
    * model/ppgn_indnoise_multdim.py: the learned scalar of layer l on the diagonal of an extra input channel).  Nullable.
    * [L][B] floats on the device: before layer l runs, layer_cond[l][b] is written on the whole diagonal of channel H-1 of its
    * INPUT planes.  The caller passes the variant's (H-1)-wide matrices zero-padded to H (pad row / column H-1, zero bias), so
-   * that channel is identically zero everywhere else.  Inference only: dppm_ppgn_backward rejects a non-null layer_cond. */
+   * that channel is identically zero everywhere else.  In a grads struct handed to dppm_ppgn_backward the same field is the
+   * OUTPUT buffer [L][B] that receives d/d layer_cond (required when the params struct carries layer_cond; the gradients of
+   * the pad rows / columns of the padded matrices are meaningless and are to be dropped by the caller). */
   const float* layer_cond;
 } dppm_ppgn_params;
 
@@ -161,7 +163,8 @@ int dppm_ppgn_forward(const dppm_ppgn_params* params_host, const float* A, const
 
 /* Gradients of sum(logits * dlogits) w.r.t. every parameter in *grads_host (same layout as params; every
  * buffer is overwritten).  `workspace` must be the one a dppm_ppgn_forward(training=1) call on the same inputs
- * filled.  dsigma (nullable): [B] gradient w.r.t. sigma (needed only when noise_mlp conditions sigma).
+ * filled.  dsigma (nullable): [B], receives the gradient w.r.t. sigma (needed only when a learned noise_mlp produces sigma,
+ * model/ppgn.py:273-274).
  * Replaces torch autograd over model/ppgn.py:257-337. */
 int dppm_ppgn_backward(const dppm_ppgn_params* params_host, const dppm_ppgn_params* grads_host,
                        const float* A, const float* mask, const float* sigma, int B, int N,
