@@ -168,6 +168,90 @@ def test_forward_n512_h128(ops, precision, tol):
     close(logits, ref, tol=tol)
 
 
+def _sbm(rng, N, n_active=None):
+    """SBM of the bench workload (tools/make_sbm.py constants): blocks of ~25 nodes, p_intra 0.3, p_inter 0.005."""
+    n = N if n_active is None else n_active
+    k = -(-n // 25)
+    blk = rng.integers(0, k, size=n)
+    p = np.where(blk[:, None] == blk[None, :], 0.3, 0.005)
+    up = np.triu((rng.random((n, n)) < p).astype(np.float32), 1)
+    for i in range(n - 1):
+        up[i, i + 1] = 1          # every node active (degree > 0)
+    A = np.zeros((N, N), np.float32)
+    A[:n, :n] = up + up.T
+    return A
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16x3", 1e-3)])
+def test_full_size_properties_n200_8x128(ops, precision, tol):
+    """Size-independent properties of the denoiser at the bench geometry (N = 200, 8 x 128), where the float64 oracle is too slow
+    to be the checker: (a) permutation equivariance f(P A P^T) = P f(A) P^T; (b) a graph's logits do not depend on its batch
+    neighbours; (c) padding invariance: n = 150 active nodes padded to N = 200 give the logits of the unpadded N = 150 call;
+    (d) the whole batch is finite and carries nothing outside the mask's support after masking."""
+    from oracle import ppgn as op
+    L, H, N, B = 8, 128, 200, 4
+    rng = np.random.default_rng(200)
+    W = op.init_weights(L, H, seed=1234)
+    A = np.stack([_sbm(rng, N), _sbm(rng, N), _sbm(rng, N, 150), _sbm(rng, N, 101)])
+    flags = (A.sum(-1) > 1e-5).astype(np.float32)
+    mask = flags[:, :, None] * flags[:, None, :]
+    sigma = np.asarray([0.05, 0.3, 0.2, 0.45])
+    base, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    assert np.isfinite(base).all()
+    scale = np.abs(base * mask).max()
+    # (a) a random relabelling of every graph's active nodes
+    Ap, perms = np.zeros_like(A), []
+    for b in range(B):
+        n = int(flags[b].sum())
+        perm = np.concatenate([rng.permutation(n), np.arange(n, N)])
+        perms.append(perm)
+        Ap[b] = A[b][np.ix_(perm, perm)]
+    got, _ = run_gpu(ops, W, Ap, mask, sigma, L, H, precision=precision)
+    for b in range(B):
+        want = base[b][np.ix_(perms[b], perms[b])]
+        err = np.abs((got[b] - want) * mask[b]).max()
+        assert err <= tol * scale, f"equivariance, graph {b}: {err:.3e} vs scale {scale:.3e}"
+    # (b) graph 2 alone
+    alone, _ = run_gpu(ops, W, A[2:3], mask[2:3], sigma[2:3], L, H, precision=precision)
+    assert np.abs((alone[0] - base[2]) * mask[2]).max() <= 1e-6 * scale
+    # (c) the same graph without its padding
+    small, _ = run_gpu(ops, W, A[2:3, :150, :150], mask[2:3, :150, :150], sigma[2:3], L, H, precision=precision)
+    err = np.abs(small[0] - base[2, :150, :150]).max()
+    assert err <= tol * scale, f"padding invariance: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_backward_linearity_n200_8x128(ops):
+    """The backward pass is linear in dlogits: grads(R1 + 2 R2) = grads(R1) + 2 grads(R2) at the bench geometry (float32 rounding
+    of sums over 1.3 M positions, cancelling almost completely for the biases that sit in front of an instance norm: 1e-3 of each
+    tensor's scale, the north star's float32 tolerance), and a zero dlogits gives exactly zero gradients."""
+    from oracle import ppgn as op
+    L, H, N, B = 8, 128, 200, 2
+    rng = np.random.default_rng(201)
+    W = op.init_weights(L, H, seed=1234)
+    A = np.stack([_sbm(rng, N), _sbm(rng, N, 160)])
+    flags = (A.sum(-1) > 1e-5).astype(np.float32)
+    mask = flags[:, :, None] * flags[:, None, :]
+    sigma = np.asarray([0.1, 0.4])
+    R1 = rng.normal(size=A.shape).astype(np.float32) * mask
+    R2 = rng.normal(size=A.shape).astype(np.float32) * mask
+    _, g1 = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R1)
+    _, g2 = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R2)
+    _, g12 = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R1 + 2 * R2)
+    _, g0 = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=np.zeros_like(R1))
+    gmax = max(np.abs(v).max() for v in g12.values())
+    for k in g12:
+        assert np.all(g0[k] == 0), k
+        if k.endswith("m4.0.bias"):
+            # a constant added in front of an instance norm is removed by it: this gradient is zero in exact arithmetic, what is
+            # left is the rounding of a 1.3 M-term sum (nothing to be linear in)
+            assert np.abs(g12[k]).max() <= 5e-4 * gmax, f"{k}: {np.abs(g12[k]).max():.3e} vs gmax {gmax:.3e}"
+            continue
+        want = g1[k].astype(np.float64) + 2 * g2[k].astype(np.float64)
+        scale = max(np.abs(want).max(), 2e-2 * gmax)
+        err = np.abs(g12[k] - want).max()
+        assert err <= 1e-3 * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
+
+
 def test_inference_equals_training_forward(ops):
     from oracle import ppgn as op
     rng = np.random.default_rng(3)
