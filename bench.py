@@ -258,7 +258,7 @@ def main():
             "exact_f32": exact,
             "train": train,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the host-core baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(N, H, L, T)
         print(json.dumps(line))
     if world > 1:
