@@ -176,6 +176,13 @@ def train_step_vlb(model, state, adj, t_idx, T, seed, offset, graph_id0=0, group
 
 
 # ---------------------------------------------------------------------------------------------- sampling chains
+def _sigma_rows(levels, like):
+    """[T, B] float32 on the device, row c = the noise level of chain step c for every graph: one host-to-device copy per chain
+    instead of one (stream-synchronising) copy per level; the values are the float32 roundings model._prepare would make."""
+    col = torch.as_tensor(np.asarray(levels, dtype=np.float64).astype(np.float32), device=like.device)
+    return col.view(-1, 1).expand(-1, like.shape[0]).contiguous()
+
+
 @torch.no_grad()
 def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None):
     """x_T ~ Bern(1/2), then for sigma descending: re-noise x0_hat to sigma, predict flips, sample, XOR
@@ -184,9 +191,11 @@ def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None)
     x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
     a_t = torch.empty_like(x)
     logits = torch.empty_like(x)
-    for c, sigma in enumerate(schedule_simple(noise_num)):
+    sched = schedule_simple(noise_num)
+    sig_rows = _sigma_rows(sched, x)
+    for c, sigma in enumerate(sched):
         ops.edgeflip(x, flags, sigma, seed=seed, graph_id0=graph_id0, offset=1 + 2 * c, want_target=False, out=a_t)
-        model.infer(a_t, mask, sigma, out=logits)
+        model.infer(a_t, mask, sig_rows[c], out=logits)
         ops.reverse_step_simple(a_t, logits, flags, seed=seed, graph_id0=graph_id0, offset=2 + 2 * c, out=x)
         if record is not None:
             record(c, a_t, logits, x)
@@ -200,8 +209,10 @@ def sample_chain_vlb(model, flags, noise_num, seed, graph_id0=0, record=None):
     x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
     y = torch.empty_like(x)
     logits = torch.empty_like(x)
-    for c, (st, beta, st1) in enumerate(schedule_vlb(noise_num)):
-        model.infer(x, mask, st, out=logits)
+    sched = schedule_vlb(noise_num)
+    sig_rows = _sigma_rows([st for st, _, _ in sched], x)
+    for c, (st, beta, st1) in enumerate(sched):
+        model.infer(x, mask, sig_rows[c], out=logits)
         ops.reverse_step_vlb(x, logits, flags, st, beta, st1, seed=seed, graph_id0=graph_id0, offset=1 + c, out=y)
         if record is not None:
             record(c, x, logits, y)
