@@ -4,6 +4,7 @@
 #include "dppm_wstat.h"
 #include "dppm_wsplit.h"
 #include "w3_mlp_dma.h"
+#include "w3_mlp_wide.h"
 #include <vector>
 #include <cstdio>
 #include <cmath>
@@ -72,6 +73,11 @@ int main(int argc, char** argv) {
     hipMemset(Y0, 0, S * 4); hipMemset(Y1, 0, S * 4);
     add("bf16x3 mlp pair LDS-DMA", 4 * unit, 3 * SB, [=] { return w3d_mlp_forward(md, 0); });
     cmp("dma vs x3 o1", Z0, Y0, S); cmp("dma vs x3 o2", Z1, Y1, S); }
+  { WsArgs md = m3; md.job[0].Y = Y0; md.job[1].Y = Y1;
+    hipMemset(Y0, 0, S * 4); hipMemset(Y1, 0, S * 4);
+    add("bf16x3 mlp pair wide", 4 * unit, 3 * SB, [=] { return w3w_mlp_forward<3, 1>(md, 0); });
+    cmp("wide vs x3 o1", Z0, Y0, S); cmp("wide vs x3 o2", Z1, Y1, S);
+    add("bf16x3 mlp pair wide d2", 4 * unit, 3 * SB, [=] { return w3w_mlp_forward<3, 2>(md, 0); }); }
   add("bf16x3 mlp pair depth2", 4 * unit, 3 * SB, [&] { return w3_mlp_forward<3, 2>(m3, 0); });
   add("bf16 mlp pair depth1", 4 * unit, 3 * SB, [&] { return w3_mlp_forward<1, 1>(m3, 0); });
   hipMemset(Z0, 0, S * 4); hipMemset(Z1, 0, S * 4);
