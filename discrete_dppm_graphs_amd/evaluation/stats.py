@@ -4,8 +4,9 @@
 On a GPU the default evaluator computes the reference's `degree` and `cluster` MMDs (degree / clustering-coefficient
 histograms, Gaussian-EMD kernel, evaluation/stats.py:41-69, :140-186, evaluation/mmd.py:32-41, :90-106) with the HIP
 kernels of csrc/dppm_stats.hip, so periodic model selection does not stall training on
-networkx / pyemd loops.  The `orbit` MMD (ORCA subprocess) and the SBM likelihood (graph_tool) stay out of scope; register
-the reference's own evaluator (or any other) with `set_evaluator(fn)` to get them.  Without a GPU the default is a
+networkx / pyemd loops.  The `orbit` MMD (evaluation/stats.py:210-273, an ORCA subprocess in the reference) is computed from
+closed forms over dense matrix products (`orbit_totals`, torch on the device); the SBM likelihood (graph_tool) stays out of
+scope; register the reference's own evaluator (or any other) with `set_evaluator(fn)` to get it.  Without a GPU the default is a
 numpy degree-histogram MMD (Gaussian-TV kernel)."""
 import numpy as np
 
@@ -57,11 +58,63 @@ def degree_mmd(ref, pred):
     return float(k(a, a) + k(b, b) - 2 * k(a, b))
 
 
+def orbit_totals(adj, chunk=64):
+    """[G, 15] float64: per graph, the sums over nodes of the 15 orbit counts of the connected 2-, 3- and 4-node graphlets
+    (what `orca node 4` prints per node, summed; Przulj's orbit numbering).  adj: [G, N, N] 0/1 tensor (any device).
+    Non-induced subgraph counts from degrees, A^2, A^4's trace and per-edge common-neighbour counts, K4 from the triangles inside
+    every neighbourhood, then inclusion-exclusion to induced counts.  All arithmetic in float64 on integers (exact below 2^53)."""
+    import torch
+    A = (adj > 0.5).to(torch.float64)
+    G, N, _ = A.shape
+    A = A * (1.0 - torch.eye(N, dtype=torch.float64, device=A.device))
+    d = A.sum(-1)                                             # [G, N]
+    m = d.sum(-1) / 2
+    A2 = A @ A
+    te = A2 * A                                               # per ordered edge: common neighbours
+    tv = te.sum(-1) / 2                                       # triangles through each node
+    T = tv.sum(-1) / 3
+    W = (d * (d - 1) / 2).sum(-1)                             # wedges
+    S = (d * (d - 1) * (d - 2) / 6).sum(-1)                   # 3-stars
+    P = (A * ((d - 1)[:, :, None] * (d - 1)[:, None, :])).sum((-1, -2)) / 2 - 3 * T      # 3-edge paths
+    C = ((A2 * A2).sum((-1, -2)) - 4 * W - 2 * m) / 8         # 4-cycles (trace(A^4) = sum of squares of A^2)
+    TT = (tv * (d - 2)).sum(-1)                               # triangle + pendant edge
+    D = (te * (te - 1) / 2).sum((-1, -2)) / 2                 # two triangles sharing an edge
+    K = torch.zeros(G, dtype=torch.float64, device=A.device)  # K4 = (1/4) sum_i triangles inside N(i)
+    Af = A.to(torch.float32)                                  # entries of the masked squares are <= N: exact in float32
+    for g in range(G):
+        acc = torch.zeros((), dtype=torch.float64, device=A.device)
+        for i0 in range(0, N, chunk):
+            nb = Af[g, i0:i0 + chunk]                         # [c, N] neighbourhood indicators
+            M = Af[g][None] * nb[:, :, None] * nb[:, None, :]   # [c, N, N] adjacency inside each neighbourhood
+            acc += ((M @ M) * M).to(torch.float64).sum() / 6
+        K[g] = acc / 4
+    diam = D - 6 * K
+    c4 = C - D + 3 * K
+    paw = TT - 4 * diam - 12 * K
+    claw = S - paw - 2 * diam - 4 * K
+    p4 = P - 4 * c4 - 2 * paw - 6 * diam - 12 * K
+    p3 = W - 3 * T
+    return torch.stack([2 * m, 2 * p3, p3, 3 * T, 2 * p4, 2 * p4, 3 * claw, claw, 4 * c4, paw, 2 * paw, paw, 2 * diam, 2 * diam, 4 * K], dim=-1)
+
+
+def orbit_mmd_batch(ref_batch, pred_batch, sigma=30.0):
+    """reference orbit_stats_all (evaluation/stats.py:239-273) on dense batches: totals / #non-isolated nodes, Gaussian kernel on
+    the raw 15-vectors (util/dist_helper.py:91-96, is_hist=False), compute_mmd."""
+    import torch
+
+    def feats(b):
+        nn = ((b > 0.5).sum(-1) > 0).sum(-1).clamp(min=1).to(torch.float64)
+        return orbit_totals(b) / nn[:, None]
+    x, y = feats(ref_batch), feats(pred_batch)
+    k = lambda p, q: torch.exp(-torch.cdist(p, q).pow(2) / (2 * sigma * sigma)).mean()
+    return k(x, x) + k(y, y) - 2 * k(x, y)
+
+
 def eval_torch_batch(ref_batch, pred_batch, methods=None, bins=100):
     """reference evaluation/stats.py:340-344 on the device: ref_batch / pred_batch are [G, N, N] adjacency tensors (cuda).
-    Returns {'degree': mmd, 'cluster': mmd} as python floats (one host sync at the end)."""
+    Returns {'degree': mmd, 'cluster': mmd, 'orbit': mmd} as python floats (one host sync at the end)."""
     from .. import ops
-    methods = list(methods) if methods is not None else ['degree', 'cluster']
+    methods = list(methods) if methods is not None else ['degree', 'cluster', 'orbit']
     n = max(ref_batch.shape[-1], pred_batch.shape[-1])
 
     import torch
@@ -77,6 +130,8 @@ def eval_torch_batch(ref_batch, pred_batch, methods=None, bins=100):
         out['degree'] = ops.mmd_gaussian_emd(d1, d2, sigma=1.0, distance_scaling=1.0)[0]
     if 'cluster' in methods:
         out['cluster'] = ops.mmd_gaussian_emd(c1, c2, sigma=1.0 / 10, distance_scaling=float(bins))[0]
+    if 'orbit' in methods:
+        out['orbit'] = orbit_mmd_batch(ref_batch, pred_batch)
     return {k: float(v.item()) for k, v in out.items()}
 
 
@@ -96,7 +151,7 @@ def eval_graph_list(graph_ref_list, graph_pred_list, methods=None):
         return _EVALUATOR(graph_ref_list, graph_pred_list, methods=methods)
     import torch
     if torch.cuda.is_available():
-        want = [m for m in (methods or ['degree', 'cluster']) if m in ('degree', 'cluster')]
+        want = [m for m in (methods or ['degree', 'cluster', 'orbit']) if m in ('degree', 'cluster', 'orbit')]
         return eval_torch_batch(torch.from_numpy(_dense_batch(graph_ref_list)).cuda(),
                                 torch.from_numpy(_dense_batch(graph_pred_list)).cuda(), methods=want)
     return {"degree": degree_mmd(graph_ref_list, graph_pred_list)}

@@ -58,3 +58,64 @@ def eval_adjs(ref, pred, bins=100):
     return {"degree": compute_mmd([degree_histogram(a) for a in ref], [degree_histogram(a) for a in pred]),
             "cluster": compute_mmd([clustering_histogram(a, bins) for a in ref], [clustering_histogram(a, bins) for a in pred],
                                    sigma=1.0 / 10, distance_scaling=bins)}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Orbit statistic (reference evaluation/stats.py:210-273).  The reference shells out to ORCA ("orca node 4": per-node counts of
+# the 15 orbits of the connected 2-, 3- and 4-node graphlets, Przulj's numbering) and keeps only the per-graph column sums divided
+# by the number of (non-isolated) nodes.  The restatement below is the DEFINITION of those counts (enumeration of every node subset).
+# Parity: PINNED by tests/golden/g7_orbits.npz, the output of the reference's own ORCA SOURCE (evaluation/orca/orca.cpp) compiled
+# here by oracle/Makefile into oracle/_ref/orca (tests/golden/gen_golden_orbits.py); the prebuilt binary in the reference is never run.
+# ---------------------------------------------------------------------------------------------------------
+def orbit_totals_bruteforce(adj):
+    """[15] sums over nodes of the orbit counts of a dense 0/1 adjacency (python loops: small graphs only)."""
+    from itertools import combinations
+    a = (np.asarray(adj) > 0.5)
+    a = a & ~np.eye(a.shape[0], dtype=bool)
+    n = a.shape[0]
+    out = np.zeros(15, np.int64)
+    out[0] = a.sum()                                   # every edge puts both its ends on orbit 0
+    for s in combinations(range(n), 3):
+        sub = a[np.ix_(s, s)]
+        deg = sub.sum(1)
+        e = deg.sum() // 2
+        if e == 2:                                     # induced path: ends on orbit 1, middle on orbit 2
+            out[1] += 2; out[2] += 1
+        elif e == 3:
+            out[3] += 3
+    for s in combinations(range(n), 4):
+        sub = a[np.ix_(s, s)]
+        deg = np.sort(sub.sum(1))
+        e = deg.sum() // 2
+        key = tuple(deg)
+        if e == 3 and key == (1, 1, 2, 2):             # path: ends 4, middle 5
+            out[4] += 2; out[5] += 2
+        elif e == 3 and key == (1, 1, 1, 3):           # claw: leaves 6, centre 7
+            out[6] += 3; out[7] += 1
+        elif e == 4 and key == (2, 2, 2, 2):           # cycle
+            out[8] += 4
+        elif e == 4 and key == (1, 2, 2, 3):           # tailed triangle: tail end 9, far triangle nodes 10, junction 11
+            out[9] += 1; out[10] += 2; out[11] += 1
+        elif e == 5:                                   # diamond: degree-2 nodes 12, degree-3 nodes 13
+            out[12] += 2; out[13] += 2
+        elif e == 6:
+            out[14] += 4
+    return out
+
+
+def orbit_mmd(ref_adjs, pred_adjs, totals=orbit_totals_bruteforce, sigma=30.0):
+    """evaluation/stats.py:239-273: per-graph totals / #non-isolated nodes, Gaussian kernel (util/dist_helper.py:91-96) on the raw
+    15-vectors (is_hist=False), MMD as compute_mmd."""
+    def feats(adjs):
+        rows = []
+        for a in adjs:
+            a = np.asarray(a)
+            nn = max(int(((a > 0.5).sum(-1) > 0).sum()), 1)
+            rows.append(totals(a).astype(np.float64) / nn)
+        return np.asarray(rows)
+    x, y = feats(ref_adjs), feats(pred_adjs)
+
+    def k(p, q):
+        d2 = ((p[:, None, :] - q[None, :, :]) ** 2).sum(-1)
+        return np.exp(-d2 / (2 * sigma * sigma)).mean()
+    return float(k(x, x) + k(y, y) - 2 * k(x, y))

@@ -71,3 +71,16 @@ def test_mmd_matches_oracle_and_eval_hooks():
     lst = ev.eval_graph_list(ev.adjs_to_graphs(ref), ev.adjs_to_graphs(pred))
     for k in ("degree", "cluster"):
         assert abs(lst[k] - want[k]) <= 1e-12 + 1e-10 * abs(want[k])
+
+
+def test_orbit_mmd_on_device_matches_oracle():
+    from discrete_dppm_graphs_amd.evaluation import stats as ev
+    from oracle import stats as os_
+    rng = np.random.default_rng(5)
+    ref = _adjs(rng, 6, 14, 0.4)
+    pred = _adjs(rng, 5, 14, 0.6)
+    want = os_.orbit_mmd(list(ref), list(pred))
+    got = ev.eval_torch_batch(torch.from_numpy(ref).cuda(), torch.from_numpy(pred).cuda(), methods=["orbit"])
+    assert abs(got["orbit"] - want) <= 1e-12
+    lst = ev.eval_graph_list(ev.adjs_to_graphs(ref), ev.adjs_to_graphs(pred))
+    assert set(lst) == {"degree", "cluster", "orbit"} and abs(lst["orbit"] - want) <= 1e-12
