@@ -15,6 +15,7 @@
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
 #include "dppm_planesplit.h"
+#include "dppm_smallgraph.h"
 #include <cstdlib>
 
 namespace dppm {
@@ -614,6 +615,9 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   const Layout& w = c.w;
   DPPM_REQUIRE(workspace_bytes >= w.total * sizeof(float), "dppm_ppgn_forward: workspace %zu < %zu bytes", workspace_bytes,
                w.total * sizeof(float));
+  // small graphs (N <= 20, hidden 32: the reference's ego_small / community_small networks), inference: one launch, one workgroup
+  // per graph, activations in registers and LDS (dppm_smallgraph.hip); the workspace stays untouched
+  if (sg_supported(pr, N, training)) return sg_forward(pr, A, mask, sigma, B, N, logits, c.st);
   const int P = w.P;
   const long cat_bs = (long)w.CT * P, hs = (long)H * P;
   float* maskp = c.at(w.maskp);

@@ -1,0 +1,469 @@
+// Whole-graph-per-workgroup PPGN forward for the reference's own small configurations (ego_small N = 18, community_small
+// N = 20: hidden 32, config/train_ego_small_ddpm.yaml) -- inference only, exact float32 (v_mfma_f32_16x16x4_f32).
+//
+// At N <= 20, H = 32 one graph's activations are 32 x 400 floats = 51 KB, so the ~45 launches per denoiser call of the
+// general path (8 us each, launch-latency bound: 0.38 ms per level) collapse into ONE launch in which a 16-wave workgroup
+// carries a graph through every layer of model/ppgn.py:257-337 without touching HBM in between:
+//   * the layer input u lives in REGISTERS in the MFMA result layout (lane (q, n) of a wave: channels 16 co + 4 q + r,
+//     co = 0..1, r = 0..3, at position 16 t + n of the wave's position tile t).  The order of a contraction's k steps is
+//     free, so a result tile is fed back as the B operand of the next product unchanged: k step (ci, r) pairs the lane's
+//     register [ci][r] with the weight W[row][16 ci + 4 q + r] (one 16-byte LDS read per four steps).  Linear ->
+//     LeakyReLU -> Linear (m1, m2), the skip half of m4, the readout accumulation (layer_cat_lin, never materialising the
+//     cat) and after_conv all chain through registers;
+//   * only the operands of the per-channel contraction need whole planes: o1, o2 [32][N][ld] sit in LDS (pitch 404: both the
+//     result-layout writes and the B-operand reads are bank-conflict free), wave w contracts channels 2w, 2w+1 on
+//     16x16x4 tiles and writes the product over o1;
+//   * the masked instance norm is two block reductions over the m4 result held in registers (mean, then variance around it,
+//     util/model_helper.py:182-189);
+//   * the layer's weights (32 KB) sit in LDS; the next layer's are fetched into 8 registers per thread while this one runs.
+// One workgroup per graph; LDS 141.6 KB of the 160 KB a CU has.
+#include "dppm_smallgraph.h"
+#include <cstdlib>
+
+namespace dppm {
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr float kSlopeSg = 0.01f;   // LeakyReLU negative slope, model/ppgn.py:7
+
+constexpr int SG_PITCH = 404;       // floats between channel planes (== 4 mod 64)
+constexpr int SG_NW = 8;             // waves per workgroup (256 VGPRs each: u, the readout accumulators and the m4 result of four tiles stay in registers)
+constexpr int SG_TPW = 4;           // position tiles per wave: 25 tiles of 16 positions at N = 20
+constexpr int SG_THREADS = 64 * SG_NW;
+constexpr int SG_SPM = 1024 / SG_THREADS;   // prefetch slots per 32 x 32 matrix
+constexpr int SG_NPF = 7 * SG_SPM + 5;
+constexpr int SG_CPW = 32 / SG_NW;   // channels per wave in the contraction
+constexpr int SG_WP = 36;           // LDS row pitch of a 32-wide matrix
+constexpr int SG_WP4 = 68;          // ... of m4 (64 wide)
+constexpr int SG_W_M1A = 0, SG_W_M1B = 1152, SG_W_M2A = 2304, SG_W_M2B = 3456, SG_W_CAT = 4608, SG_W_M4 = 5760;
+constexpr int SG_W_BIAS = 7936;     // m1_b0, m1_b1, m2_b0, m2_b1, m4_b (32 each)
+constexpr int SG_W_TOTAL = 8096;
+constexpr int SG_MP = 416;          // padded mask plane
+constexpr int SG_LDS_FLOATS = 2 * 32 * SG_PITCH + SG_W_TOTAL + SG_MP + 2 * SG_NW * 32 + 64;
+
+// Diagnostic build only (-DSG_STAMP): s_memtime at the phase boundaries of layer 2, wave 0 and wave 1 of workgroup 0
+#ifdef SG_STAMP
+__device__ unsigned long long sg_stamps[64];
+#define SG_T(i) do { if (l == 2 && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && w < 2) { __builtin_amdgcn_sched_barrier(0); sg_stamps[16 * w + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SG_T(i) do {} while (0)
+#endif
+
+struct SgArgs {
+  dppm_ppgn_layer layer[SG_MAX_LAYERS];
+  const float *in_w, *in_b, *cat_w, *cat_b, *after_w, *after_b, *final_w, *final_b;
+  const float *A, *mask, *sigma;
+  float* logits;
+  int L, N, ld, P, CT;
+};
+
+// next layer's weights -> SG_NPF registers per thread (coalesced dword loads; the tensors need no alignment); l == L: the head
+__device__ __forceinline__ void sg_prefetch(float (&pf)[SG_NPF], const SgArgs& a, int l, int tid) {
+  // branch-free: for the head (l == L) the first matrix is after_conv and the rest re-reads the last layer (committed again, unused)
+  const int lc = l < a.L ? l : a.L - 1;
+  const dppm_ppgn_layer& q = a.layer[lc];
+  const float* p0 = l < a.L ? q.m1_w0 : a.after_w;
+#pragma unroll
+  for (int h = 0; h < SG_SPM; ++h) {
+    const int idx = tid + SG_THREADS * h;
+    pf[h] = p0[idx]; pf[SG_SPM + h] = q.m1_w1[idx]; pf[2 * SG_SPM + h] = q.m2_w0[idx]; pf[3 * SG_SPM + h] = q.m2_w1[idx];
+    pf[4 * SG_SPM + h] = a.cat_w[(size_t)(idx >> 5) * a.CT + 2 + 32 * lc + (idx & 31)];
+    pf[5 * SG_SPM + h] = q.m4_w[idx]; pf[6 * SG_SPM + h] = q.m4_w[1024 + idx];
+  }
+  const int c = tid & 31;   // every thread loads the biases (uniform pointers, no branch); threads < 32 commit them
+  pf[7 * SG_SPM] = q.m1_b0[c]; pf[7 * SG_SPM + 1] = q.m1_b1[c]; pf[7 * SG_SPM + 2] = q.m2_b0[c];
+  pf[7 * SG_SPM + 3] = q.m2_b1[c]; pf[7 * SG_SPM + 4] = q.m4_b[c];
+}
+__device__ __forceinline__ void sg_commit(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
+#pragma unroll
+  for (int h = 0; h < SG_SPM; ++h) {
+    const int idx = tid + SG_THREADS * h;
+    const int o = (idx >> 5) * SG_WP + (idx & 31);
+    W[SG_W_M1A + o] = pf[h];
+    W[SG_W_M1B + o] = pf[SG_SPM + h]; W[SG_W_M2A + o] = pf[2 * SG_SPM + h]; W[SG_W_M2B + o] = pf[3 * SG_SPM + h];
+    W[SG_W_CAT + o] = pf[4 * SG_SPM + h];
+    const int o4 = (idx >> 6) * SG_WP4 + (idx & 63);
+    W[SG_W_M4 + o4] = pf[5 * SG_SPM + h]; W[SG_W_M4 + 16 * SG_WP4 + o4] = pf[6 * SG_SPM + h];
+  }
+  if (tid < 32) {
+    W[SG_W_BIAS + tid] = pf[7 * SG_SPM]; W[SG_W_BIAS + 32 + tid] = pf[7 * SG_SPM + 1]; W[SG_W_BIAS + 64 + tid] = pf[7 * SG_SPM + 2];
+    W[SG_W_BIAS + 96 + tid] = pf[7 * SG_SPM + 3]; W[SG_W_BIAS + 128 + tid] = pf[7 * SG_SPM + 4];
+  }
+}
+
+// acc[co] (channels 16 co + 4 q + r at the lane's position) += Wm[:, c0 .. c0 + 31] * src, src in the same layout
+__device__ __forceinline__ void sg_mma(floatx4 (&acc)[2], const float* __restrict__ Wm, int wp, int c0, const floatx4 (&src)[2], int q, int n) {
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    float4 wv[2];
+#pragma unroll
+    for (int co = 0; co < 2; ++co) wv[co] = *reinterpret_cast<const float4*>(Wm + (16 * co + n) * wp + c0 + 16 * ci + 4 * q);
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+      acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].x, src[ci][0], acc[co], 0, 0, 0);
+      acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].y, src[ci][1], acc[co], 0, 0, 0);
+      acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].z, src[ci][2], acc[co], 0, 0, 0);
+      acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].w, src[ci][3], acc[co], 0, 0, 0);
+    }
+  }
+}
+// the same product for every position tile the wave owns (NTL of them): the weight fragments are read once
+template <int NTL>
+__device__ __forceinline__ void sg_mma_all(floatx4 (&acc)[SG_TPW][2], const float* __restrict__ Wm, int wp, int c0,
+                                           const floatx4 (&src)[SG_TPW][2], int q, int n) {
+  float4 wv[2][2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int co = 0; co < 2; ++co) wv[ci][co] = *reinterpret_cast<const float4*>(Wm + (16 * co + n) * wp + c0 + 16 * ci + 4 * q);
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    if (ti >= NTL) continue;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int co = 0; co < 2; ++co) {
+        acc[ti][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ci][co].x, src[ti][ci][0], acc[ti][co], 0, 0, 0);
+        acc[ti][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ci][co].y, src[ti][ci][1], acc[ti][co], 0, 0, 0);
+        acc[ti][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ci][co].z, src[ti][ci][2], acc[ti][co], 0, 0, 0);
+        acc[ti][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ci][co].w, src[ti][ci][3], acc[ti][co], 0, 0, 0);
+      }
+  }
+}
+__device__ __forceinline__ floatx4 sg_bias(const float* __restrict__ bv, int co, int q) {   // bias of channels 16 co + 4 q .. + 3
+  const float4 t = *reinterpret_cast<const float4*>(bv + 16 * co + 4 * q);
+  floatx4 r; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  return r;
+}
+__device__ __forceinline__ float sg_leaky(float v) { return v > 0.f ? v : kSlopeSg * v; }
+
+// sum over the 16 lanes that share q (the positions of a tile), for the lane's 8 channels
+__device__ __forceinline__ void sg_sum16(floatx4 (&s)[2]) {
+#pragma unroll
+  for (int co = 0; co < 2; ++co)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = s[co][r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      s[co][r] = v;
+    }
+}
+// partial sums of every wave -> totals per channel (all threads)
+__device__ __forceinline__ void sg_block_totals(floatx4 (&s)[2], float* __restrict__ red, int w, int q, int n) {
+  sg_sum16(s);
+  if (n == 0) {
+#pragma unroll
+    for (int co = 0; co < 2; ++co) *reinterpret_cast<float4*>(red + w * 32 + 16 * co + 4 * q) = make_float4(s[co][0], s[co][1], s[co][2], s[co][3]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int co = 0; co < 2; ++co) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < SG_NW; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(red + k * 32 + 16 * co + 4 * q);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    s[co][0] = t.x; s[co][1] = t.y; s[co][2] = t.z; s[co][3] = t.w;
+  }
+}
+
+// NTL = number of position tiles of the calling wave (a compile-time constant keeps every phase one straight-line block, so the
+// epilogue arithmetic of one product interleaves with the MFMAs of the next); every variant passes the same barriers
+template <int NTL, bool TWO>
+__device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_lds) {
+  float* O1 = sg_lds;
+  float* O2 = O1 + 32 * SG_PITCH;
+  float* W = O2 + 32 * SG_PITCH;
+  float* mp = W + SG_W_TOTAL;
+  float* red1 = mp + SG_MP;
+  float* red2 = red1 + SG_NW * 32;
+  float* dump = red2 + SG_NW * 32;
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane >> 4, n = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile ownership tests become scalar branches
+  const int N = a.N, ld = a.ld, P = a.P, L = a.L;
+  const int ntile = (P + 15) >> 4;
+  // the wave owns position tiles w + SG_NW * ti, ti < SG_TPW, as far as they exist (ntile <= 25)
+#define SG_TILE(ti) (w + SG_NW * (ti))
+#define SG_HAS(ti) ((ti) < NTL)
+
+  float pf[SG_NPF];
+  sg_prefetch(pf, a, 0, tid);
+  if (tid < SG_MP) {
+    const int i = tid / ld, j = tid - i * ld;
+    mp[tid] = (tid < P && j < N) ? a.mask[((size_t)b * N + i) * N + j] : 0.f;
+  }
+  __syncthreads();
+  float cpart = tid < SG_MP ? mp[tid] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cpart += __shfl_xor(cpart, o, 64);
+  if (lane == 0) red1[w] = cpart;
+  sg_commit(pf, W, tid);
+  __syncthreads();
+  float cnt = 0.f;
+#pragma unroll
+  for (int k = 0; k < SG_NW; ++k) cnt += red1[k];
+  float s0 = 0.f;
+  for (int j = 0; j < ld; ++j) s0 += mp[j];
+  const float inv_norm = 1.f / sqrtf(s0);           // model/ppgn.py:51: mask row 0
+
+  // input planes [A, sigma I], in_lin (model/ppgn.py:283-301) and the [A, sigma I] columns of layer_cat_lin (:318,327)
+  floatx4 u[SG_TPW][2], yacc[SG_TPW][2];
+  float mt[SG_TPW];
+  const float sg = a.sigma[b];
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    const int pos = 16 * SG_TILE(ti) + n;
+    const bool tv = SG_HAS(ti);
+    const int i = pos / ld, j = pos - i * ld;
+    const bool in = tv && pos < P && j < N;
+    const float av = in ? a.A[((size_t)b * N + i) * N + j] : 0.f;
+    const float sv = (in && i == j) ? sg : 0.f;
+    mt[ti] = tv ? mp[pos] : 0.f;
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * co + 4 * q + r;
+        u[ti][co][r] = a.in_w[2 * ch] * av + a.in_w[2 * ch + 1] * sv + a.in_b[ch];
+        yacc[ti][co][r] = a.cat_w[(size_t)ch * a.CT] * av + a.cat_w[(size_t)ch * a.CT + 1] * sv + a.cat_b[ch];
+      }
+  }
+
+  for (int l = 0; l < L; ++l) {
+    sg_prefetch(pf, a, l + 1, tid);                  // next layer's weights (the head's after the last layer): in flight while this layer runs
+    SG_T(0);
+    // ---- m1, m2: Linear -> LeakyReLU -> Linear, * mask (model/ppgn.py:58-59), hidden activations in registers
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      floatx4 h[SG_TPW][2], o[SG_TPW][2];
+#pragma unroll
+      for (int ti = 0; ti < SG_TPW; ++ti) { h[ti][0] = h[ti][1] = o[ti][0] = o[ti][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+      sg_mma_all<NTL>(h, W + (k ? SG_W_M2A : SG_W_M1A), SG_WP, 0, u, q, n);
+#pragma unroll
+      for (int co = 0; co < 2; ++co) {
+        const floatx4 bv = sg_bias(W + SG_W_BIAS + (k ? 64 : 0), co, q);
+#pragma unroll
+        for (int ti = 0; ti < SG_TPW; ++ti)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[ti][co][r] = sg_leaky(h[ti][co][r] + bv[r]);
+      }
+      sg_mma_all<NTL>(o, W + (k ? SG_W_M2B : SG_W_M1B), SG_WP, 0, h, q, n);
+      float* Ok = k ? O2 : O1;
+#pragma unroll
+      for (int co = 0; co < 2; ++co) {
+        const floatx4 bv = sg_bias(W + SG_W_BIAS + (k ? 96 : 32), co, q);
+#pragma unroll
+        for (int ti = 0; ti < SG_TPW; ++ti) {
+          if (ti >= NTL) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ok[(16 * co + 4 * q + r) * SG_PITCH + 16 * SG_TILE(ti) + n] = (o[ti][co][r] + bv[r]) * mt[ti];
+        }
+      }
+    }
+    SG_T(1);
+    __syncthreads();
+    SG_T(2);
+
+    // ---- per-channel contraction o1[c] @ o2[c] / sqrt(n) (model/ppgn.py:62-64): SG_CPW channels per wave; result over o1[c]
+    {
+      // k runs over ld = 4 * ksteps <= 20 columns (pad columns hold zeros): all operand reads of the wave's channels are issued
+      // up front (fixed trip count 5, steps beyond ld contribute zeros), then the MFMAs run back to back
+      constexpr bool two = TWO;                       // N > 16: 2 x 2 output tiles per channel
+      const int i0 = min(n, N - 1), i1 = min(16 + n, N - 1), j0 = min(n, ld - 1), j1 = min(16 + n, ld - 1);
+      // software pipeline over the wave's channels: the operand reads of channel c + 1 are in flight while channel c multiplies
+      float a0[5], a1[5], b0[5], b1[5], na0[5], na1[5], nb0[5], nb1[5];
+      auto fetch = [&](int c, float (&fa0)[5], float (&fa1)[5], float (&fb0)[5], float (&fb1)[5]) {
+        const float* pa = O1 + (SG_CPW * w + c) * SG_PITCH;
+        const float* pb = O2 + (SG_CPW * w + c) * SG_PITCH;
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+          const bool live = 4 * ks < ld;
+          const int k = live ? 4 * ks + q : q;
+          const float va0 = pa[i0 * ld + k], vb0 = pb[k * ld + j0];
+          fa0[ks] = live ? va0 : 0.f; fb0[ks] = live ? vb0 : 0.f;
+          fa1[ks] = 0.f; fb1[ks] = 0.f;
+          if (two) {
+            const float va1 = pa[i1 * ld + k], vb1 = pb[k * ld + j1];
+            fa1[ks] = live ? va1 : 0.f; fb1[ks] = live ? vb1 : 0.f;
+          }
+        }
+      };
+      fetch(0, a0, a1, b0, b1);
+#pragma unroll 1
+      for (int c = 0; c < SG_CPW; ++c) {
+        fetch(c + 1 < SG_CPW ? c + 1 : c, na0, na1, nb0, nb1);
+        float* pa = O1 + (SG_CPW * w + c) * SG_PITCH;
+        floatx4 acc[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], b0[ks], acc[0][0], 0, 0, 0);
+          if (two) {
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], b1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], b0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], b1[ks], acc[1][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            if ((x || y) && !two) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * x + 4 * q + r, j = 16 * y + n;
+              const bool ok = i < N && j < ld;             // branch-free: lanes outside the plane write to their dump slot
+              (ok ? pa + i * ld + j : dump + lane)[0] = acc[x][y][r] * inv_norm;
+            }
+          }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) { a0[ks] = na0[ks]; a1[ks] = na1[ks]; b0[ks] = nb0[ks]; b1[ks] = nb1[ks]; }
+      }
+    }
+    SG_T(3);
+    __syncthreads();
+    SG_T(4);
+
+    // ---- m4 on cat(mm, x) (model/ppgn.py:66-69), masked instance norm, * mask (util/model_helper.py:176-191, ppgn.py:315)
+    floatx4 y[SG_TPW][2];
+    floatx4 s[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+    {
+      floatx4 ms[SG_TPW][2];
+#pragma unroll
+      for (int ti = 0; ti < SG_TPW; ++ti) {
+        y[ti][0] = y[ti][1] = ms[ti][0] = ms[ti][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (ti >= NTL) continue;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ms[ti][ci][r] = O1[(16 * ci + 4 * q + r) * SG_PITCH + 16 * SG_TILE(ti) + n];
+      }
+      sg_mma_all<NTL>(y, W + SG_W_M4, SG_WP4, 0, ms, q, n);
+    }
+    sg_mma_all<NTL>(y, W + SG_W_M4, SG_WP4, 32, u, q, n);
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+      const floatx4 bv = sg_bias(W + SG_W_BIAS + 128, co, q);
+#pragma unroll
+      for (int ti = 0; ti < SG_TPW; ++ti) {
+        if (ti >= NTL) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          y[ti][co][r] += bv[r];
+          s[co][r] += y[ti][co][r] * mt[ti];
+        }
+      }
+    }
+    SG_T(5);
+    sg_block_totals(s, red1, w, q, n);
+    SG_T(6);
+    floatx4 mean[2], qs[2];
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mean[co][r] = s[co][r] / cnt;
+        float acc = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < SG_TPW; ++ti) {
+          const float d = (y[ti][co][r] - mean[co][r]) * mt[ti];
+          acc += d * d;
+        }
+        qs[co][r] = acc;
+      }
+    sg_block_totals(qs, red2, w, q, n);
+    SG_T(7);
+#pragma unroll
+    for (int ti = 0; ti < SG_TPW; ++ti)
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float rstd = 1.f / sqrtf(qs[co][r] / cnt + 1e-5f);
+          u[ti][co][r] = (y[ti][co][r] - mean[co][r]) * rstd * mt[ti];
+        }
+    // ---- this layer's columns of layer_cat_lin (model/ppgn.py:318,327)
+    sg_mma_all<NTL>(yacc, W + SG_W_CAT, SG_WP, 0, u, q, n);
+    SG_T(8);
+    __syncthreads();                                   // every wave is done with this layer's weights
+    sg_commit(pf, W, tid);
+    __syncthreads();
+    SG_T(9);
+  }
+
+  // ---- head: out + LeakyReLU(after_conv(out)), final_lin (model/ppgn.py:331-333; dropout is the identity in eval)
+  const float fb = a.final_b[0];
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    if (!SG_HAS(ti)) continue;
+    const int pos = 16 * SG_TILE(ti) + n;
+    floatx4 act[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+    sg_mma(act, W + SG_W_M1A, SG_WP, 0, yacc[ti], q, n);
+    float part = 0.f;
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * co + 4 * q + r;
+        part += a.final_w[ch] * (yacc[ti][co][r] + sg_leaky(act[co][r] + a.after_b[ch]));
+      }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    const int i = pos / ld, j = pos - i * ld;
+    if (q == 0 && pos < P && j < N) a.logits[((size_t)b * N + i) * N + j] = part + fb;
+  }
+}
+
+__global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sg_lds[];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntile = (a.P + 15) >> 4;
+  const int ntl = w < ntile ? (ntile - w + SG_NW - 1) / SG_NW : 0;   // the wave owns tiles w + SG_NW * ti, ti < ntl
+  const bool two = a.N > 16;
+  switch (ntl) {
+    case 4: if (two) sg_run<4, true>(a, sg_lds); else sg_run<4, false>(a, sg_lds); break;
+    case 3: if (two) sg_run<3, true>(a, sg_lds); else sg_run<3, false>(a, sg_lds); break;
+    case 2: if (two) sg_run<2, true>(a, sg_lds); else sg_run<2, false>(a, sg_lds); break;
+    case 1: if (two) sg_run<1, true>(a, sg_lds); else sg_run<1, false>(a, sg_lds); break;
+    default: if (two) sg_run<0, true>(a, sg_lds); else sg_run<0, false>(a, sg_lds); break;
+  }
+}
+
+}  // namespace
+
+bool sg_supported(const dppm_ppgn_params* pr, int N, int training) {
+  const bool off = getenv("DPPM_DISABLE_SMALLGRAPH") != nullptr;   // A/B switch for measurements and tests (read per call)
+  return !off && !training && pr->hidden == 32 && N >= 1 && N <= SG_MAX_NODES && pr->num_layers <= SG_MAX_LAYERS && !pr->layer_cond;
+}
+
+int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
+               hipStream_t st) {
+  SgArgs a{};
+  for (int l = 0; l < pr->num_layers; ++l) a.layer[l] = pr->layers_host[l];
+  a.in_w = pr->in_w; a.in_b = pr->in_b; a.cat_w = pr->cat_w; a.cat_b = pr->cat_b;
+  a.after_w = pr->after_w; a.after_b = pr->after_b; a.final_w = pr->final_w; a.final_b = pr->final_b;
+  a.A = A; a.mask = mask; a.sigma = sigma; a.logits = logits;
+  a.L = pr->num_layers; a.N = N; a.ld = round_up(N, 4); a.P = N * a.ld; a.CT = 2 + 32 * pr->num_layers;
+  const size_t lds = SG_LDS_FLOATS * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "sg_forward: cannot reserve %zu bytes of LDS", lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sg_forward_kernel, dim3(B), dim3(SG_THREADS), lds, st, a);
+  return check_launch("sg_forward");
+}
+
+}  // namespace dppm
+
+#ifdef SG_STAMP
+extern "C" int dppm_sg_read_stamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(dppm::sg_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+}
+#endif

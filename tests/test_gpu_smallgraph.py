@@ -1,0 +1,67 @@
+"""Whole-graph-per-workgroup PPGN forward (csrc/dppm_smallgraph.hip: N <= 20, hidden 32, inference, one launch) through
+dppm_ppgn_forward, against the oracle and against the general multi-launch path (DPPM_DISABLE_SMALLGRAPH=1) on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_ppgn import close, dev, rand_case, run_gpu
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from discrete_dppm_graphs_amd import ops
+    return ops
+
+
+def _general(ops, *args):
+    os.environ["DPPM_DISABLE_SMALLGRAPH"] = "1"
+    try:
+        return run_gpu(ops, *args)[0]
+    finally:
+        del os.environ["DPPM_DISABLE_SMALLGRAPH"]
+
+
+@pytest.mark.parametrize("B,N,L", [(1, 1, 1), (2, 2, 2), (3, 4, 1), (2, 5, 3), (4, 12, 2), (3, 16, 6), (5, 17, 2), (32, 18, 6), (32, 20, 6),
+                                   (2, 20, 16), (70, 19, 1)])
+def test_fused_forward_vs_oracle_and_general_path(ops, B, N, L):
+    from oracle import ppgn as op
+    rng = np.random.default_rng(100 * N + L)
+    A, mask = rand_case(rng, B, N, ragged=N >= 6)
+    if N < 6:                                        # tiny graphs: every node active, arbitrary edges
+        up = np.triu(rng.random((B, N, N)) < 0.5, 1).astype(np.float32)
+        A = up + up.transpose(0, 2, 1)
+        mask = np.ones((B, N, N), np.float32)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, 32, seed=N)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, 32)
+    close(got, ref)                                  # padded positions carry the reference's unmasked values too
+    close(got, _general(ops, W, A, mask, sigma, L, 32), tol=5e-5)
+
+
+def test_fused_forward_golden_reference_logits(ops):
+    """The reference's own logits for ego_small's geometry (N = 18, 6 x 32), one sigma for the whole batch."""
+    g = np.load(os.path.join(G, "g1_ppgn_n18_h32_l6.npz"))
+    from discrete_dppm_graphs_amd.ops import used_param_names
+    W = {n: g["w::" + n] for n in used_param_names(6)}
+    lb, _ = run_gpu(ops, W, g["A_t"], g["mask"], float(g["sigmas"][0]), 6, 32)
+    close(lb, g["logits_batched_sigma0"])
+
+
+def test_fused_forward_is_deterministic_and_batch_independent(ops):
+    from oracle import ppgn as op
+    rng = np.random.default_rng(7)
+    A, mask = rand_case(rng, 9, 20)
+    sigma = rng.uniform(0, 0.5, size=9)
+    W = op.init_weights(6, 32, seed=3)
+    a, _ = run_gpu(ops, W, A, mask, sigma, 6, 32)
+    b, _ = run_gpu(ops, W, A, mask, sigma, 6, 32)
+    assert np.array_equal(a, b)
+    c, _ = run_gpu(ops, W, A[4:5], mask[4:5], sigma[4:5], 6, 32)
+    assert np.array_equal(a[4:5], c)                 # one workgroup per graph: no dependence on the rest of the batch
