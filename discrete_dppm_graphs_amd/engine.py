@@ -176,6 +176,15 @@ def train_step_vlb(model, state, adj, t_idx, T, seed, offset, graph_id0=0, group
 
 
 # ---------------------------------------------------------------------------------------------- sampling chains
+def chain_width(model, N, B, n_batches, cus=256):
+    """How many of the reference's sampling batches (test.batch_size graphs each, run_sample's `while` loop,
+    sample_ppgn_simple.py:72-88) one chain call may carry.  Where the denoiser runs one workgroup per graph (N <= 20, hidden 32:
+    csrc/dppm_smallgraph.hip) a call's latency does not depend on the batch until every CU holds a graph, so consecutive batches
+    ride one call; graph ids are global, hence the samples are the same either way."""
+    small = N <= 20 and getattr(model, "hidden", None) == 32 and type(model).__name__ == "Powerful"
+    return max(1, min(n_batches, cus // max(B, 1))) if small else 1
+
+
 def _sigma_rows(levels, like):
     """[T, B] float32 on the device, row c = the noise level of chain step c for every graph: one host-to-device copy per chain
     instead of one (stream-synchronising) copy per level; the values are the float32 roundings model._prepare would make."""

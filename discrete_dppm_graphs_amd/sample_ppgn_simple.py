@@ -61,6 +61,12 @@ def run_sample(config, model, pool_adjs, eval_len, noise_num, chain, ref_graphs,
     _CALLS["n"] += 1
     n_batches = -(-eval_len // B)
     idx = [np.random.randint(0, len(pool_adjs), B) for _ in range(n_batches)]   # every rank draws all, keeps its own
+    m = engine.chain_width(model, pool_adjs.shape[-1], B, -(-n_batches // world))
+    if m > 1:       # small graphs: m consecutive batches per chain call (same graph ids, same samples)
+        idx = [np.concatenate(idx[k:k + m]) for k in range(0, n_batches, m)]
+        if len(idx[-1]) < m * B:                                                 # ragged tail: pad with repeats, cut after the gather
+            idx[-1] = np.concatenate([idx[-1], np.resize(idx[-1], m * B - len(idx[-1]))])
+        n_graphs, n_batches, B = n_batches * B, len(idx), m * B
     mine = []
     with torch.no_grad():
         for bi in my_batches(n_batches, rank, world):
@@ -70,6 +76,8 @@ def run_sample(config, model, pool_adjs, eval_len, noise_num, chain, ref_graphs,
     N = pool_adjs.shape[-1]
     mine = torch.cat(mine) if mine else torch.zeros(0, N, N, dtype=torch.uint8, device=dev)
     allg = gather_batches(mine, n_batches, B, rank, world, dist)
+    if m > 1:
+        allg = allg[:n_graphs]
     gen_graph_list = adjs_to_graphs(allg.cpu().numpy().astype(np.float32))
     result_dict = eval_graph_list(ref_graphs, gen_graph_list, methods=methods)
     return result_dict, gen_graph_list

@@ -155,6 +155,8 @@ size_t dppm_ppgn_workspace_bytes(int B, int N, int H, int L, int training);
  * training batch run in one call).  mask: [B][N][N], binary, node 0 of every graph active (the reference divides
  * by sqrt(sum_j mask[b][0][j]), model/ppgn.py:51).
  * precision: DPPM_PREC_* (see above); ignored (exact float32) when training != 0.
+ * Inference with hidden = 32, N <= 20 and no layer_cond (the reference's ego_small / community_small networks) runs as ONE launch,
+ * one workgroup per graph, exact float32, and leaves the workspace untouched (csrc/dppm_smallgraph.hip).
  * Replaces model/ppgn.py:257-337 Powerful.forward/forward_cat, :47-71 PowerfulLayer.forward and
  * util/model_helper.py:176-191 masked_instance_norm2D. */
 int dppm_ppgn_forward(const dppm_ppgn_params* params_host, const float* A, const float* mask, const float* sigma,

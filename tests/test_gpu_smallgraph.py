@@ -65,3 +65,39 @@ def test_fused_forward_is_deterministic_and_batch_independent(ops):
     assert np.array_equal(a, b)
     c, _ = run_gpu(ops, W, A[4:5], mask[4:5], sigma[4:5], 6, 32)
     assert np.array_equal(a[4:5], c)                 # one workgroup per graph: no dependence on the rest of the batch
+
+
+def test_run_sample_carries_several_batches_per_chain_call(monkeypatch):
+    """Small graphs: run_sample merges consecutive reference batches into one chain call (engine.chain_width); the generated
+    graphs are exactly those of the batch-by-batch loop, ragged tail included."""
+    import types
+    from discrete_dppm_graphs_amd import engine, sample_ppgn_simple as sps
+    from discrete_dppm_graphs_amd.model.ppgn import Powerful
+    torch.manual_seed(5)
+    model = Powerful(num_layers=3, hidden=32, hidden_final=32, n_nodes=18, normalization="instance", adj_out=True, input_features=2,
+                     dropout_p=1e-6).cuda().eval()
+    rng = np.random.default_rng(11)
+    pool, _ = rand_case(rng, 12, 18)
+    pool = torch.from_numpy(pool)
+    cfg = types.SimpleNamespace(test=types.SimpleNamespace(batch_size=4), dev="cuda", seed=77)
+    calls = []
+
+    def chain(model, flags, T, seed, graph_id0=0):
+        calls.append(flags.shape[0])
+        return engine.sample_chain_simple(model, flags, T, seed, graph_id0=graph_id0)
+
+    got = {}
+    monkeypatch.setattr(sps, "eval_graph_list", lambda ref, gen, methods=None: {})
+    monkeypatch.setattr(sps, "adjs_to_graphs", lambda a: a)
+    for width in ("merged", "single"):
+        if width == "single":
+            monkeypatch.setattr(engine, "chain_width", lambda *a, **k: 1)
+        np.random.seed(3)
+        sps._CALLS["n"] = 0
+        calls.clear()
+        _, gen = sps.run_sample(cfg, model, pool, 22, 6, chain, None)
+        got[width] = (np.asarray(gen).copy(), list(calls))
+    assert got["merged"][1] == [24] and got["single"][1] == [4] * 6
+    assert got["merged"][0].shape[0] == 24 - 2 or got["merged"][0].shape[0] == 24      # 22 asked: 6 batches of 4 drawn, as the reference does
+    assert np.array_equal(got["merged"][0][:22], got["single"][0][:22])
+    assert got["merged"][0][:22].sum() > 0
