@@ -31,7 +31,7 @@ constexpr int SG_NW = 8;             // waves per workgroup (256 VGPRs each: u, 
 constexpr int SG_TPW = 4;           // position tiles per wave: 25 tiles of 16 positions at N = 20
 constexpr int SG_THREADS = 64 * SG_NW;
 constexpr int SG_SPM = 1024 / SG_THREADS;   // prefetch slots per 32 x 32 matrix
-constexpr int SG_NPF = 7 * SG_SPM + 5;
+constexpr int SG_NPF = 4 * SG_SPM + 4;   // registers per thread that carry weights towards LDS
 constexpr int SG_CPW = 32 / SG_NW;   // channels per wave in the contraction
 constexpr int SG_WP = 36;           // LDS row pitch of a 32-wide matrix
 constexpr int SG_WP4 = 68;          // ... of m4 (64 wide)
@@ -57,9 +57,14 @@ struct SgArgs {
   int L, N, ld, P, CT;
 };
 
-// next layer's weights -> SG_NPF registers per thread (coalesced dword loads; the tensors need no alignment); l == L: the head
-__device__ __forceinline__ void sg_prefetch(float (&pf)[SG_NPF], const SgArgs& a, int l, int tid) {
-  // branch-free: for the head (l == L) the first matrix is after_conv and the rest re-reads the last layer (committed again, unused)
+// Weights travel global -> registers -> LDS in two groups that share the registers (coalesced dword loads; the tensors need no
+// alignment; branch-free with uniform pointers):
+//   group A = the MLP matrices and biases of layer l (for l == L: after_conv in the first slot, the rest re-reads the last layer),
+//             fetched after the MLP phase of layer l - 1 has passed its barrier and committed before that layer's last barrier;
+//   group B = m4, the layer's columns of layer_cat_lin and m4's bias, fetched at the top of layer l and committed after the MLP
+//             phase's barrier (every wave is then past the readout of layer l - 1), read after the contraction's barrier.
+// No barrier exists for the weights alone.
+__device__ __forceinline__ void sg_fetch_a(float (&pf)[SG_NPF], const SgArgs& a, int l, int tid) {
   const int lc = l < a.L ? l : a.L - 1;
   const dppm_ppgn_layer& q = a.layer[lc];
   const float* p0 = l < a.L ? q.m1_w0 : a.after_w;
@@ -67,28 +72,41 @@ __device__ __forceinline__ void sg_prefetch(float (&pf)[SG_NPF], const SgArgs& a
   for (int h = 0; h < SG_SPM; ++h) {
     const int idx = tid + SG_THREADS * h;
     pf[h] = p0[idx]; pf[SG_SPM + h] = q.m1_w1[idx]; pf[2 * SG_SPM + h] = q.m2_w0[idx]; pf[3 * SG_SPM + h] = q.m2_w1[idx];
-    pf[4 * SG_SPM + h] = a.cat_w[(size_t)(idx >> 5) * a.CT + 2 + 32 * lc + (idx & 31)];
-    pf[5 * SG_SPM + h] = q.m4_w[idx]; pf[6 * SG_SPM + h] = q.m4_w[1024 + idx];
   }
-  const int c = tid & 31;   // every thread loads the biases (uniform pointers, no branch); threads < 32 commit them
-  pf[7 * SG_SPM] = q.m1_b0[c]; pf[7 * SG_SPM + 1] = q.m1_b1[c]; pf[7 * SG_SPM + 2] = q.m2_b0[c];
-  pf[7 * SG_SPM + 3] = q.m2_b1[c]; pf[7 * SG_SPM + 4] = q.m4_b[c];
+  const int c = tid & 31;   // every thread loads the biases (no branch); threads < 32 commit them
+  pf[4 * SG_SPM] = q.m1_b0[c]; pf[4 * SG_SPM + 1] = q.m1_b1[c]; pf[4 * SG_SPM + 2] = q.m2_b0[c]; pf[4 * SG_SPM + 3] = q.m2_b1[c];
 }
-__device__ __forceinline__ void sg_commit(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
+__device__ __forceinline__ void sg_commit_a(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
 #pragma unroll
   for (int h = 0; h < SG_SPM; ++h) {
     const int idx = tid + SG_THREADS * h;
     const int o = (idx >> 5) * SG_WP + (idx & 31);
-    W[SG_W_M1A + o] = pf[h];
-    W[SG_W_M1B + o] = pf[SG_SPM + h]; W[SG_W_M2A + o] = pf[2 * SG_SPM + h]; W[SG_W_M2B + o] = pf[3 * SG_SPM + h];
-    W[SG_W_CAT + o] = pf[4 * SG_SPM + h];
-    const int o4 = (idx >> 6) * SG_WP4 + (idx & 63);
-    W[SG_W_M4 + o4] = pf[5 * SG_SPM + h]; W[SG_W_M4 + 16 * SG_WP4 + o4] = pf[6 * SG_SPM + h];
+    W[SG_W_M1A + o] = pf[h]; W[SG_W_M1B + o] = pf[SG_SPM + h]; W[SG_W_M2A + o] = pf[2 * SG_SPM + h]; W[SG_W_M2B + o] = pf[3 * SG_SPM + h];
   }
   if (tid < 32) {
-    W[SG_W_BIAS + tid] = pf[7 * SG_SPM]; W[SG_W_BIAS + 32 + tid] = pf[7 * SG_SPM + 1]; W[SG_W_BIAS + 64 + tid] = pf[7 * SG_SPM + 2];
-    W[SG_W_BIAS + 96 + tid] = pf[7 * SG_SPM + 3]; W[SG_W_BIAS + 128 + tid] = pf[7 * SG_SPM + 4];
+    W[SG_W_BIAS + tid] = pf[4 * SG_SPM]; W[SG_W_BIAS + 32 + tid] = pf[4 * SG_SPM + 1];
+    W[SG_W_BIAS + 64 + tid] = pf[4 * SG_SPM + 2]; W[SG_W_BIAS + 96 + tid] = pf[4 * SG_SPM + 3];
   }
+}
+__device__ __forceinline__ void sg_fetch_b(float (&pf)[SG_NPF], const SgArgs& a, int l, int tid) {
+  const dppm_ppgn_layer& q = a.layer[l];
+#pragma unroll
+  for (int h = 0; h < SG_SPM; ++h) {
+    const int idx = tid + SG_THREADS * h;
+    pf[h] = a.cat_w[(size_t)(idx >> 5) * a.CT + 2 + 32 * l + (idx & 31)];
+    pf[SG_SPM + h] = q.m4_w[idx]; pf[2 * SG_SPM + h] = q.m4_w[1024 + idx];
+  }
+  pf[3 * SG_SPM] = q.m4_b[tid & 31];
+}
+__device__ __forceinline__ void sg_commit_b(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
+#pragma unroll
+  for (int h = 0; h < SG_SPM; ++h) {
+    const int idx = tid + SG_THREADS * h;
+    W[SG_W_CAT + (idx >> 5) * SG_WP + (idx & 31)] = pf[h];
+    const int o4 = (idx >> 6) * SG_WP4 + (idx & 63);
+    W[SG_W_M4 + o4] = pf[SG_SPM + h]; W[SG_W_M4 + 16 * SG_WP4 + o4] = pf[2 * SG_SPM + h];
+  }
+  if (tid < 32) W[SG_W_BIAS + 128 + tid] = pf[3 * SG_SPM];
 }
 
 // acc[co] (channels 16 co + 4 q + r at the lane's position) += Wm[:, c0 .. c0 + 31] * src, src in the same layout
@@ -189,7 +207,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
 #define SG_HAS(ti) ((ti) < NTL)
 
   float pf[SG_NPF];
-  sg_prefetch(pf, a, 0, tid);
+  sg_fetch_a(pf, a, 0, tid);
   if (tid < SG_MP) {
     const int i = tid / ld, j = tid - i * ld;
     mp[tid] = (tid < P && j < N) ? a.mask[((size_t)b * N + i) * N + j] : 0.f;
@@ -199,7 +217,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cpart += __shfl_xor(cpart, o, 64);
   if (lane == 0) red1[w] = cpart;
-  sg_commit(pf, W, tid);
+  sg_commit_a(pf, W, tid);
   __syncthreads();
   float cnt = 0.f;
 #pragma unroll
@@ -232,7 +250,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
   }
 
   for (int l = 0; l < L; ++l) {
-    sg_prefetch(pf, a, l + 1, tid);                  // next layer's weights (the head's after the last layer): in flight while this layer runs
+    sg_fetch_b(pf, a, l, tid);                       // m4 / readout weights of this layer: in flight during the MLP phase
     SG_T(0);
     // ---- m1, m2: Linear -> LeakyReLU -> Linear, * mask (model/ppgn.py:58-59), hidden activations in registers
 #pragma unroll
@@ -265,6 +283,8 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
     SG_T(1);
     __syncthreads();
     SG_T(2);
+    sg_commit_b(pf, W, tid);                         // every wave is past the previous layer's readout
+    sg_fetch_a(pf, a, l + 1, tid);                   // next layer's MLP weights (after_conv after the last layer): in flight from here
 
     // ---- per-channel contraction o1[c] @ o2[c] / sqrt(n) (model/ppgn.py:62-64): SG_CPW channels per wave; result over o1[c]
     {
@@ -362,6 +382,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
     SG_T(5);
     sg_block_totals(s, red1, w, q, n);
     SG_T(6);
+    sg_commit_a(pf, W, tid);                         // the MLP phase of this layer is long over; the next barrier publishes it
     floatx4 mean[2], qs[2];
 #pragma unroll
     for (int co = 0; co < 2; ++co)
@@ -390,9 +411,6 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
     // ---- this layer's columns of layer_cat_lin (model/ppgn.py:318,327)
     sg_mma_all<NTL>(yacc, W + SG_W_CAT, SG_WP, 0, u, q, n);
     SG_T(8);
-    __syncthreads();                                   // every wave is done with this layer's weights
-    sg_commit(pf, W, tid);
-    __syncthreads();
     SG_T(9);
   }
 
