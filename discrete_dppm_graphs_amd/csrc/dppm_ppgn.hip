@@ -44,8 +44,8 @@ inline size_t bump(size_t& off, size_t n) {
 
 inline int wgrad_nsplit(int B, int P) {   // K chunks per graph so that ~1024 workgroups exist
   int per = cdiv(1024, B);
-  int kchunk = round_up(cdiv(P, per), 64);   // small planes (N = 20: P = 400) split into 64-position chunks: 4 K steps per workgroup
-  if (kchunk < 64) kchunk = 64;              // instead of 16 (the K loop of a 32 x 32 output is pure latency)
+  int kchunk = round_up(cdiv(P, per), 256);
+  if (kchunk < 256) kchunk = 256;
   return cdiv(P, kchunk);
 }
 inline int wgrad_kchunk(int B, int P) { return round_up(cdiv(P, wgrad_nsplit(B, P)), BK); }
