@@ -629,9 +629,15 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   const Layout& w = c.w;
   DPPM_REQUIRE(workspace_bytes >= w.total * sizeof(float), "dppm_ppgn_forward: workspace %zu < %zu bytes", workspace_bytes,
                w.total * sizeof(float));
-  // small graphs (N <= 20, hidden 32: the reference's ego_small / community_small networks), inference: one launch, one workgroup
-  // per graph, activations in registers and LDS (dppm_smallgraph.hip); the workspace stays untouched
-  if (sg_supported(pr, N, training)) return sg_forward(pr, A, mask, sigma, B, N, logits, c.st);
+  // small graphs (N <= 20, hidden 32: the reference's ego_small / community_small networks): one launch, one workgroup per graph,
+  // activations in registers and LDS (dppm_smallgraph.hip).  Inference leaves the workspace untouched; training writes into it
+  // exactly what dppm_ppgn_backward reads.
+  if (sg_supported(pr, N)) {
+    if (!training) return sg_forward(pr, A, mask, sigma, B, N, logits, nullptr, c.st);
+    SgSave sv{c.at(w.maskp), c.at(w.inv_norm), c.at(w.cat), c.at(w.u0), c.at(w.hid1), c.at(w.hid2), c.at(w.o1), c.at(w.o2), c.at(w.mm),
+              c.at(w.rstd), c.at(w.R), c.at(w.act), w.S};
+    return sg_forward(pr, A, mask, sigma, B, N, logits, &sv, c.st);
+  }
   const int P = w.P;
   const long cat_bs = (long)w.CT * P, hs = (long)H * P;
   float* maskp = c.at(w.maskp);

@@ -155,6 +155,22 @@ __device__ __forceinline__ floatx4 sg_bias(const float* __restrict__ bv, int co,
 }
 __device__ __forceinline__ float sg_leaky(float v) { return v > 0.f ? v : kSlopeSg * v; }
 
+// training: the wave's tiles of a [32][P] plane set of this graph -> HBM (16 lanes = 64 consecutive bytes of one channel).
+// so[ti] = 4 q P + position of the lane in tile ti (or ~0u when outside the plane): uniform pointer + 32-bit lane offset keeps the
+// address arithmetic in scalar registers
+template <int NTL>
+__device__ __forceinline__ void sg_store_tiles(float* __restrict__ base, int P, const floatx4 (&v)[SG_TPW][2], const unsigned (&so)[SG_TPW]) {
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    if (ti >= NTL) continue;
+    if (so[ti] != ~0u) {
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (base + (16 * co + r) * P)[so[ti]] = v[ti][co][r];
+    }
+  }
+}
 // sum over the 16 lanes that share q (the positions of a tile), for the lane's 8 channels
 __device__ __forceinline__ void sg_sum16(floatx4 (&s)[2]) {
 #pragma unroll
@@ -186,10 +202,8 @@ __device__ __forceinline__ void sg_block_totals(floatx4 (&s)[2], float* __restri
   }
 }
 
-// NTL = number of position tiles of the calling wave (a compile-time constant keeps every phase one straight-line block, so the
-// epilogue arithmetic of one product interleaves with the MFMAs of the next); every variant passes the same barriers
-template <int NTL, bool TWO>
-__device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_lds) {
+template <int NTL, bool TWO, bool SAVE>
+__device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float* __restrict__ sg_lds) {
   float* O1 = sg_lds;
   float* O2 = O1 + 32 * SG_PITCH;
   float* W = O2 + 32 * SG_PITCH;
@@ -237,16 +251,32 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
     const int i = pos / ld, j = pos - i * ld;
     const bool in = tv && pos < P && j < N;
     const float av = in ? a.A[((size_t)b * N + i) * N + j] : 0.f;
-    const float sv = (in && i == j) ? sg : 0.f;
+    const float sgv = (in && i == j) ? sg : 0.f;
     mt[ti] = tv ? mp[pos] : 0.f;
 #pragma unroll
     for (int co = 0; co < 2; ++co)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ch = 16 * co + 4 * q + r;
-        u[ti][co][r] = a.in_w[2 * ch] * av + a.in_w[2 * ch + 1] * sv + a.in_b[ch];
-        yacc[ti][co][r] = a.cat_w[(size_t)ch * a.CT] * av + a.cat_w[(size_t)ch * a.CT + 1] * sv + a.cat_b[ch];
+        u[ti][co][r] = a.in_w[2 * ch] * av + a.in_w[2 * ch + 1] * sgv + a.in_b[ch];
+        yacc[ti][co][r] = a.cat_w[(size_t)ch * a.CT] * av + a.cat_w[(size_t)ch * a.CT + 1] * sgv + a.cat_b[ch];
       }
+    if (SAVE && tv && pos < P && q == 0) {             // the input planes of CAT and the padded mask
+      sv.cat[(size_t)b * a.CT * P + pos] = av;
+      sv.cat[(size_t)b * a.CT * P + P + pos] = sgv;
+      sv.maskp[(size_t)b * P + pos] = mt[ti];
+    }
+  }
+  const size_t gS = (size_t)b * 32 * P;                // this graph inside a [B][32][P] plane set
+  unsigned so[SG_TPW];
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    const int pos = 16 * SG_TILE(ti) + n;
+    so[ti] = (SG_HAS(ti) && pos < P) ? (unsigned)(4 * q * P + pos) : ~0u;
+  }
+  if (SAVE) {
+    if (tid == 0) sv.inv_norm[b] = inv_norm;
+    sg_store_tiles<NTL>(sv.u0 + gS, P, u, so);
   }
 
   for (int l = 0; l < L; ++l) {
@@ -267,6 +297,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[ti][co][r] = sg_leaky(h[ti][co][r] + bv[r]);
       }
+      if (SAVE) sg_store_tiles<NTL>((k ? sv.hid2 : sv.hid1) + (size_t)l * sv.S + gS, P, h, so);
       sg_mma_all<NTL>(o, W + (k ? SG_W_M2B : SG_W_M1B), SG_WP, 0, h, q, n);
       float* Ok = k ? O2 : O1;
 #pragma unroll
@@ -276,9 +307,13 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
         for (int ti = 0; ti < SG_TPW; ++ti) {
           if (ti >= NTL) continue;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Ok[(16 * co + 4 * q + r) * SG_PITCH + 16 * SG_TILE(ti) + n] = (o[ti][co][r] + bv[r]) * mt[ti];
+          for (int r = 0; r < 4; ++r) {
+            o[ti][co][r] = (o[ti][co][r] + bv[r]) * mt[ti];
+            Ok[(16 * co + 4 * q + r) * SG_PITCH + 16 * SG_TILE(ti) + n] = o[ti][co][r];
+          }
         }
       }
+      if (SAVE) sg_store_tiles<NTL>((k ? sv.o2 : sv.o1) + (size_t)l * sv.S + gS, P, o, so);
     }
     SG_T(1);
     __syncthreads();
@@ -339,6 +374,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
               const int i = 16 * x + 4 * q + r, j = 16 * y + n;
               const bool ok = i < N && j < ld;             // branch-free: lanes outside the plane write to their dump slot
               (ok ? pa + i * ld + j : dump + lane)[0] = acc[x][y][r] * inv_norm;
+              if (SAVE && ok) (sv.mm + (size_t)l * sv.S + gS + (size_t)(SG_CPW * w + c) * P)[(unsigned)(i * ld + j)] = acc[x][y][r] * inv_norm;
             }
           }
 #pragma unroll
@@ -407,7 +443,9 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
         for (int r = 0; r < 4; ++r) {
           const float rstd = 1.f / sqrtf(qs[co][r] / cnt + 1e-5f);
           u[ti][co][r] = (y[ti][co][r] - mean[co][r]) * rstd * mt[ti];
+          if (SAVE && ti == 0 && w == 0 && n == 0) sv.rstd[((size_t)l * gridDim.x + b) * 32 + 16 * co + 4 * q + r] = rstd;
         }
+    if (SAVE) sg_store_tiles<NTL>(sv.cat + (size_t)b * a.CT * P + (size_t)(2 + 32 * l) * P, P, u, so);
     // ---- this layer's columns of layer_cat_lin (model/ppgn.py:318,327)
     sg_mma_all<NTL>(yacc, W + SG_W_CAT, SG_WP, 0, u, q, n);
     SG_T(8);
@@ -428,7 +466,12 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ch = 16 * co + 4 * q + r;
-        part += a.final_w[ch] * (yacc[ti][co][r] + sg_leaky(act[co][r] + a.after_b[ch]));
+        const float av = sg_leaky(act[co][r] + a.after_b[ch]);
+        part += a.final_w[ch] * (yacc[ti][co][r] + av);
+        if (SAVE && so[ti] != ~0u) {
+          (sv.R + gS + (16 * co + r) * P)[so[ti]] = yacc[ti][co][r];
+          (sv.act + gS + (16 * co + r) * P)[so[ti]] = av;
+        }
       }
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
@@ -437,44 +480,48 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, float* __restrict__ sg_l
   }
 }
 
-__global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a) {
+template <bool SAVE>
+__global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, const SgSave sv) {
   extern __shared__ __attribute__((aligned(16))) float sg_lds[];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntile = (a.P + 15) >> 4;
   const int ntl = w < ntile ? (ntile - w + SG_NW - 1) / SG_NW : 0;   // the wave owns tiles w + SG_NW * ti, ti < ntl
   const bool two = a.N > 16;
   switch (ntl) {
-    case 4: if (two) sg_run<4, true>(a, sg_lds); else sg_run<4, false>(a, sg_lds); break;
-    case 3: if (two) sg_run<3, true>(a, sg_lds); else sg_run<3, false>(a, sg_lds); break;
-    case 2: if (two) sg_run<2, true>(a, sg_lds); else sg_run<2, false>(a, sg_lds); break;
-    case 1: if (two) sg_run<1, true>(a, sg_lds); else sg_run<1, false>(a, sg_lds); break;
-    default: if (two) sg_run<0, true>(a, sg_lds); else sg_run<0, false>(a, sg_lds); break;
+    case 4: if (two) sg_run<4, true, SAVE>(a, sv, sg_lds); else sg_run<4, false, SAVE>(a, sv, sg_lds); break;
+    case 3: if (two) sg_run<3, true, SAVE>(a, sv, sg_lds); else sg_run<3, false, SAVE>(a, sv, sg_lds); break;
+    case 2: if (two) sg_run<2, true, SAVE>(a, sv, sg_lds); else sg_run<2, false, SAVE>(a, sv, sg_lds); break;
+    case 1: if (two) sg_run<1, true, SAVE>(a, sv, sg_lds); else sg_run<1, false, SAVE>(a, sv, sg_lds); break;
+    default: if (two) sg_run<0, true, SAVE>(a, sv, sg_lds); else sg_run<0, false, SAVE>(a, sv, sg_lds); break;
   }
 }
 
 }  // namespace
 
-bool sg_supported(const dppm_ppgn_params* pr, int N, int training) {
+bool sg_supported(const dppm_ppgn_params* pr, int N) {
   const bool off = getenv("DPPM_DISABLE_SMALLGRAPH") != nullptr;   // A/B switch for measurements and tests (read per call)
-  return !off && !training && pr->hidden == 32 && N >= 1 && N <= SG_MAX_NODES && pr->num_layers <= SG_MAX_LAYERS && !pr->layer_cond;
+  return !off && pr->hidden == 32 && N >= 1 && N <= SG_MAX_NODES && pr->num_layers <= SG_MAX_LAYERS && !pr->layer_cond;
 }
 
 int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
-               hipStream_t st) {
+               const SgSave* save, hipStream_t st) {
   SgArgs a{};
   for (int l = 0; l < pr->num_layers; ++l) a.layer[l] = pr->layers_host[l];
   a.in_w = pr->in_w; a.in_b = pr->in_b; a.cat_w = pr->cat_w; a.cat_b = pr->cat_b;
   a.after_w = pr->after_w; a.after_b = pr->after_b; a.final_w = pr->final_w; a.final_b = pr->final_b;
   a.A = A; a.mask = mask; a.sigma = sigma; a.logits = logits;
   a.L = pr->num_layers; a.N = N; a.ld = round_up(N, 4); a.P = N * a.ld; a.CT = 2 + 32 * pr->num_layers;
+  const SgSave sv = save ? *save : SgSave{};
   const size_t lds = SG_LDS_FLOATS * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "sg_forward: cannot reserve %zu bytes of LDS", lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(sg_forward_kernel, dim3(B), dim3(SG_THREADS), lds, st, a);
+  if (save) hipLaunchKernelGGL(sg_forward_kernel<true>, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
+  else hipLaunchKernelGGL(sg_forward_kernel<false>, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
   return check_launch("sg_forward");
 }
 
