@@ -341,22 +341,28 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
 // former one-thread-per-element loop over all slabs was a chain of nz dependent loads on a handful of blocks: 15 us per call
 // at 32 x 32 outputs, 74 calls per training step of the small (6 x 32) networks = 40 % of that step.
 constexpr int RS_E = 32, RS_G = 8;
+// second (nullable) job in the same launch: out2[m] = sum_z slabs2[z][m] (the bias gradient that rides with a weight gradient)
 __global__ __launch_bounds__(RS_E * RS_G) void reduce_slabs_kernel(const float* __restrict__ slabs, int nz, int M, int N,
-                                                                 float* __restrict__ out, int ldo) {
+                                                                 float* __restrict__ out, int ldo,
+                                                                 const float* __restrict__ slabs2, float* __restrict__ out2) {
   __shared__ float part[RS_G][RS_E];
   const int g = threadIdx.x / RS_E, t = threadIdx.x % RS_E;
-  const int e = blockIdx.x * RS_E + t;
-  const size_t MN = (size_t)M * N;
+  int e = blockIdx.x * RS_E + t;
+  int MN = M * N;
+  const int nb1 = (MN + RS_E - 1) / RS_E;            // blocks of the first job
+  const bool second = (int)blockIdx.x >= nb1;        // block-uniform
+  if (second) { e -= nb1 * RS_E; slabs = slabs2; MN = M; }
   float acc = 0.f;
-  if (e < M * N)
+  if (e < MN)
     for (int z = g; z < nz; z += RS_G) acc += slabs[(size_t)z * MN + e];
   part[g][t] = acc;
   __syncthreads();
-  if (g == 0 && e < M * N) {
+  if (g == 0 && e < MN) {
     float v = part[0][t];
 #pragma unroll
     for (int k = 1; k < RS_G; ++k) v += part[k][t];
-    out[(size_t)(e / N) * ldo + (e % N)] = v;
+    if (second) out2[e] = v;
+    else out[(size_t)(e / N) * ldo + (e % N)] = v;
   }
 }
 
@@ -488,13 +494,10 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
   a.rowsum = db ? rsum : nullptr;
   a.prof_class = PROF_WGRAD;
   DPPM_TRY(launch_gemm(a, nz, false, false, c.st));
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, RS_E)), dim3(RS_E * RS_G), 0, c.st, slabs, nz, M, Nw, dW, ldo);
-  DPPM_TRY(check_launch("reduce_slabs(dW)"));
-  if (db) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(M, RS_E)), dim3(RS_E * RS_G), 0, c.st, rsum, nz, 1, M, db, M);
-    DPPM_TRY(check_launch("reduce_slabs(db)"));
-  }
-  return DPPM_OK;
+  // dW and (when asked for) db in one launch
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, RS_E) + (db ? cdiv(M, RS_E) : 0)), dim3(RS_E * RS_G), 0, c.st,
+                     (const float*)slabs, nz, M, Nw, dW, ldo, (const float*)rsum, db);
+  return check_launch("reduce_slabs(dW, db)");
 }
 int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
   if (use_wstat(M) && Nw == WS_H && c.w.slab_floats >= ws_wgrad_scratch_floats()) {   // register-resident split-K form (dppm_wgrad.h)
@@ -754,10 +757,9 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
   hipLaunchKernelGGL(final_bwd_kernel, dim3(B * H), dim3(256), 0, c.st, c.at(w.R), c.at(w.act), pr->final_w, dlogits, H, N, w.ld,
                      dh, dz, part, part + (size_t)B * H);
   DPPM_TRY(check_launch("final_bwd"));
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(H, RS_E)), dim3(RS_E * RS_G), 0, c.st, part, B, 1, H, gr->final_w, H);
-  DPPM_TRY(check_launch("reduce(dwfin)"));
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RS_E * RS_G), 0, c.st, part + (size_t)B * H, B, 1, 1, gr->final_b, 1);
-  DPPM_TRY(check_launch("reduce(dbfin)"));
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(H, RS_E) + 1), dim3(RS_E * RS_G), 0, c.st, (const float*)part, B, 1, H, gr->final_w, H,
+                     (const float*)(part + (size_t)B * H), gr->final_b);
+  DPPM_TRY(check_launch("reduce(dwfin, dbfin)"));
   DPPM_TRY(wgrad(c, H, dz, hs, H, c.at(w.R), hs, gr->after_w, H, gr->after_b));
   // dR = dh + W_ac^T dz   (accumulated into dh)
   const bool ws = use_wstat(H);
