@@ -366,6 +366,55 @@ __global__ __launch_bounds__(RS_E * RS_G) void reduce_slabs_kernel(const float* 
   }
 }
 
+// Weight gradient of a 32 x 32 Linear (the 6 x 32 networks of ego_small / community_small), one K chunk of one graph per workgroup:
+//   slab[z] (32 x 32) = dY[b][:, k0 .. k0+kc) * X[b][:, k0 .. k0+kc)^T,  rsum[z][m] = sum_k dY[b][m][k]      (z = b * nsplit + s)
+// Both operand chunks (2 x 32 x kc floats, kc <= 512) are brought into LDS with every load in flight at once, then four waves
+// take one 16 x 16 output tile each on v_mfma_f32_16x16x4_f32.  The generic split-K GEMM walks the same chunk in 16-position steps
+// of load -> LDS -> barrier -> MFMA on a 32 x 128 tile: 16.6 us per launch for this shape, 40 % of a small-network training step.
+constexpr int W32_MAXK = 512;
+__global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs,
+                                                      int P, int nsplit, int kchunk, float* __restrict__ slabs,
+                                                      float* __restrict__ rsum) {
+  extern __shared__ __attribute__((aligned(16))) float w32_lds[];
+  const int z = blockIdx.x, b = z / nsplit, s = z % nsplit;
+  const int k0 = s * kchunk, kc = min(kchunk, P - k0);          // kchunk % 16 == 0, P % 4 == 0
+  const int pitch = kchunk + 4;                                   // == 4 mod 16: fragment reads of 16 rows x 4 k are conflict-free
+  float* sA = w32_lds;
+  float* sB = w32_lds + 32 * pitch;
+  const float* gA = dY + (size_t)b * dy_bs + k0;
+  const float* gB = X + (size_t)b * x_bs + k0;
+  const int kq = kchunk / 4;
+  for (int e = threadIdx.x; e < 32 * kq; e += 256) {
+    const int r = e / kq, c4 = (e - r * kq) * 4;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+    if (c4 < kc) {
+      va = *reinterpret_cast<const float4*>(gA + (size_t)r * P + c4);
+      vb = *reinterpret_cast<const float4*>(gB + (size_t)r * P + c4);
+    }
+    *reinterpret_cast<float4*>(sA + r * pitch + c4) = va;
+    *reinterpret_cast<float4*>(sB + r * pitch + c4) = vb;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
+  const int m0 = 16 * (w >> 1), n0 = 16 * (w & 1);
+  const float* pa = sA + (m0 + n) * pitch + q;
+  const float* pb = sB + (n0 + n) * pitch + q;
+  floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f}, rs = acc;
+  const bool do_rs = rsum != nullptr && n0 == 0;                  // wave-uniform
+  for (int k = 0; k < kchunk; k += 4) {
+    const float av = pa[k];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, pb[k], acc, 0, 0, 0);
+    if (do_rs) rs = __builtin_amdgcn_mfma_f32_16x16x4f32(av, 1.f, rs, 0, 0, 0);   // every column = the row sums
+  }
+  float* out = slabs + (size_t)z * 1024;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(m0 + 4 * q + r) * 32 + n0 + n] = acc[r];
+  if (do_rs && n == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rsum[(size_t)z * 32 + m0 + 4 * q + r] = rs[r];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -482,6 +531,25 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
   const int nsplit = wgrad_nsplit(c.B, c.P), kchunk = wgrad_kchunk(c.B, c.P);
   const int nz = c.B * nsplit;
   if ((size_t)nz * M * Nw > slab_floats) return fail(DPPM_E_INVALID, "wgrad: slab buffer too small");
+  static const bool w32_off = getenv("DPPM_DISABLE_WGRAD32") != nullptr;   // A/B switch for measurements
+  if (M == 32 && Nw == 32 && kchunk <= W32_MAXK && !w32_off && aligned16(dY) && aligned16(X) && dy_bs % 4 == 0 && x_bs % 4 == 0 && c.P % 4 == 0) {
+    const size_t lds = 2 * 32 * (size_t)(kchunk + 4) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * 32 * (W32_MAXK + 4) * sizeof(float))) != hipSuccess)
+        return fail(DPPM_E_LAUNCH, "wgrad32: cannot reserve LDS");
+      attr_done = true;
+    }
+    const bool prof = prof_enabled();
+    if (prof) prof_before(c.st);
+    hipLaunchKernelGGL(wgrad32_kernel, dim3(nz), dim3(256), lds, c.st, dY, dy_bs, X, x_bs, c.P, nsplit, kchunk, slabs, db ? rsum : (float*)nullptr);
+    if (prof) prof_after(c.st, PROF_WGRAD, 2.0 * 32 * 32 * (double)c.P * c.B);
+    DPPM_TRY(check_launch("wgrad32"));
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, RS_E) + (db ? cdiv(M, RS_E) : 0)), dim3(RS_E * RS_G), 0, c.st,
+                       (const float*)slabs, nz, M, Nw, dW, ldo, (const float*)rsum, db);
+    return check_launch("reduce_slabs(dW, db)");
+  }
   GemmArgs a = base_args();
   a.seg[0].A = dY; a.seg[0].a_bs = dy_bs; a.seg[0].lda = c.P;
   a.seg[0].B = X; a.seg[0].b_bs = x_bs; a.seg[0].ldb = c.P;
