@@ -384,15 +384,26 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
   const float* gA = dY + (size_t)b * dy_bs + k0;
   const float* gB = X + (size_t)b * x_bs + k0;
   const int kq = kchunk / 4;
-  for (int e = threadIdx.x; e < 32 * kq; e += 256) {
-    const int r = e / kq, c4 = (e - r * kq) * 4;
-    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-    if (c4 < kc) {
-      va = *reinterpret_cast<const float4*>(gA + (size_t)r * P + c4);
-      vb = *reinterpret_cast<const float4*>(gB + (size_t)r * P + c4);
+  for (int e0 = threadIdx.x; e0 < 32 * kq; e0 += 4 * 256) {     // four float4 per operand in flight per thread before any LDS store
+    float4 va[4], vb[4];
+    int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + 256 * u;
+      const int r = e / kq, c4 = (e - r * kq) * 4;
+      off[u] = e < 32 * kq ? r * pitch + c4 : -1;
+      va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vb[u] = va[u];
+      if (off[u] >= 0 && c4 < kc) {
+        va[u] = *reinterpret_cast<const float4*>(gA + (size_t)r * P + c4);
+        vb[u] = *reinterpret_cast<const float4*>(gB + (size_t)r * P + c4);
+      }
     }
-    *reinterpret_cast<float4*>(sA + r * pitch + c4) = va;
-    *reinterpret_cast<float4*>(sB + r * pitch + c4) = vb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (off[u] >= 0) {
+        *reinterpret_cast<float4*>(sA + off[u]) = va[u];
+        *reinterpret_cast<float4*>(sB + off[u]) = vb[u];
+      }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
