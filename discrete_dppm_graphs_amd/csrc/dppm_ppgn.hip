@@ -426,6 +426,53 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
   }
 }
 
+// Data gradient of a 32 x 32 Linear of the small networks: Y[b][o][p] (+)= (sum_c W[c][o] * X[b][c][p]) * act'(dact[b][o][p]).
+// One wave per 16-position tile; the tile arrives in the MFMA result layout (lane (q, n): channels 16 ci + 4 q + r of position n,
+// the trick of dppm_smallgraph.hip), every load of the wave is in flight at once, 16 MFMAs, 64-byte coalesced stores.  The generic
+// GEMM spends 11 us per launch on this shape (32 x 128 tile, K loop through LDS); 37 launches per training step.
+__global__ __launch_bounds__(256) void lin32t_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ X, long x_bs,
+                                                     const float* __restrict__ dact, long dact_bs, float* __restrict__ Y, long y_bs,
+                                                     int P, int B, int accumulate) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int ntile = (P + 15) >> 4;
+  const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (id >= B * ntile) return;
+  const int b = id / ntile, pos = 16 * (id - b * ntile) + n;
+  const bool ok = pos < P;
+  const float* xb = X + (size_t)b * x_bs;
+  float* yb = Y + (size_t)b * y_bs;
+  floatx4 src[2], acc[2], da[2], old[2];
+  float wv[2][4][2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * ci + 4 * q + r;
+      src[ci][r] = ok ? xb[(size_t)c * P + pos] : 0.f;
+      da[ci][r] = (dact && ok) ? dact[(size_t)b * dact_bs + (size_t)c * P + pos] : 1.f;
+      old[ci][r] = (accumulate && ok) ? yb[(size_t)c * P + pos] : 0.f;
+#pragma unroll
+      for (int co = 0; co < 2; ++co) wv[ci][r][co] = W[(size_t)c * ldw + 16 * co + n];
+    }
+  acc[0] = acc[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int co = 0; co < 2; ++co) acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ci][r][co], src[ci][r], acc[co], 0, 0, 0);
+  if (ok) {
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[co][r];
+        if (dact) v *= da[co][r] > 0.f ? 1.f : kSlope;
+        yb[(size_t)(16 * co + 4 * q + r) * P + pos] = v + old[co][r];
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -489,6 +536,15 @@ int linear(const Ctx& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
 }
 int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const float* bias, int act, const float* mulmask,
            const float* dact, long dact_bs, float* Y, long y_bs, bool accumulate) {
+  static const bool l32_off = getenv("DPPM_DISABLE_LIN32") != nullptr;   // A/B switch for measurements
+  if (M == 32 && s0.K == 32 && s0.w_trans && !s1 && !bias && !act && !mulmask && !l32_off) {
+    const bool prof = prof_enabled();
+    if (prof) prof_before(c.st);
+    hipLaunchKernelGGL(lin32t_kernel, dim3(cdiv((long)c.B * cdiv(c.P, 16), 4)), dim3(256), 0, c.st, s0.W, s0.ldw, s0.X, s0.x_bs, dact, dact_bs,
+                       Y, y_bs, c.P, c.B, accumulate ? 1 : 0);
+    if (prof) prof_after(c.st, PROF_LINEAR, 2.0 * 32 * 32 * (double)c.P * c.B);
+    return check_launch("lin32t");
+  }
   GemmArgs a = base_args();
   const LinArgs* segs[2] = {&s0, s1};
   a.nseg = s1 ? 2 : 1;
