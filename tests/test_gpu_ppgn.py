@@ -303,7 +303,9 @@ def test_plane_matmul_reduced_precision(ops, n, precision, tol):
 
 
 @pytest.mark.parametrize("M,K,P,B", [(8, 8, 48, 2), (34, 16, 1188, 3), (64, 64, 64, 2), (40, 64, 400, 1), (128, 128, 3600, 2),
-                                     (194, 64, 64, 2), (66, 32, 400, 2), (32, 2, 400, 2), (130, 20, 132, 1)])
+                                     (194, 64, 64, 2), (66, 32, 400, 2), (32, 2, 400, 2), (130, 20, 132, 1),
+                                     # 32 x 32: the dedicated small-network kernels (lin32t_kernel, wgrad32_kernel) and their generic fallback
+                                     (32, 32, 400, 32), (32, 32, 360, 3), (32, 32, 16, 2), (32, 32, 3600, 4), (32, 32, 40000, 1), (32, 32, 1188, 70)])
 def test_linear_fwd_and_wgrad_blocks(ops, M, K, P, B):
     """Every tile configuration x operand orientation of the GEMM family, against float64 numpy."""
     rng = np.random.default_rng(M * 7 + K)
