@@ -84,6 +84,9 @@ def _load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(`make -C discrete_dppm_graphs_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU or PyTorch fallback for the DDPM hot path.")
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so); loading ours against /opt/rocm's copy before torch's is in
+    # the process leaves two runtimes side by side, and the second one reports "no ROCm-capable device"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
