@@ -473,6 +473,75 @@ __global__ __launch_bounds__(256) void lin32t_kernel(const float* __restrict__ W
   }
 }
 
+// Backward of both per-position MLPs of a small-network layer in one pass (32 x 32 matrices, torch [out][in] layout, pitch 32):
+//   dpre_k = (W1_k^T dout_k) * LeakyReLU'(hid_k)   (stored: the first-layer weight gradients read it),   dx += sum_k W0_k^T dpre_k.
+// One wave per 16-position tile; dpre_k stays in the MFMA result layout and feeds the second product from registers
+// (dppm_smallgraph.hip's chaining), so the four launches of the layer-by-layer form (11 us each on the generic GEMM) become one.
+__global__ __launch_bounds__(256) void mlp32_bwd_kernel(const float* __restrict__ do1, const float* __restrict__ do2,
+                                                        const float* __restrict__ hid1, const float* __restrict__ hid2, long hs,
+                                                        const float* __restrict__ W1a, const float* __restrict__ W1b,
+                                                        const float* __restrict__ W0a, const float* __restrict__ W0b,
+                                                        float* __restrict__ dpre1, float* __restrict__ dpre2,
+                                                        float* __restrict__ dx, long dx_bs, int P, int B) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int ntile = (P + 15) >> 4;
+  const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (id >= B * ntile) return;
+  const int b = id / ntile, pos = 16 * (id - b * ntile) + n;
+  const bool ok = pos < P;
+  const size_t g = (size_t)b * hs;
+  floatx4 accx[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}}, old[2];
+#pragma unroll
+  for (int co = 0; co < 2; ++co)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) old[co][r] = ok ? dx[(size_t)b * dx_bs + (size_t)(16 * co + 4 * q + r) * P + pos] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float* dout = k ? do2 : do1;
+    const float* hid = k ? hid2 : hid1;
+    const float* W1 = k ? W1b : W1a;
+    const float* W0 = k ? W0b : W0a;
+    float* dpre = k ? dpre2 : dpre1;
+    floatx4 src[2], hv[2], t[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+    float w1[2][4][2], w0[2][4][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * ci + 4 * q + r;
+        src[ci][r] = ok ? dout[g + (size_t)c * P + pos] : 0.f;
+        hv[ci][r] = ok ? hid[g + (size_t)c * P + pos] : 1.f;
+#pragma unroll
+        for (int co = 0; co < 2; ++co) { w1[ci][r][co] = W1[c * 32 + 16 * co + n]; w0[ci][r][co] = W0[c * 32 + 16 * co + n]; }
+      }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) t[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[ci][r][co], src[ci][r], t[co], 0, 0, 0);
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        t[co][r] *= hv[co][r] > 0.f ? 1.f : kSlope;
+        if (ok) dpre[g + (size_t)(16 * co + 4 * q + r) * P + pos] = t[co][r];
+      }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) accx[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[ci][r][co], t[ci][r], accx[co], 0, 0, 0);
+  }
+  if (ok) {
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dx[(size_t)b * dx_bs + (size_t)(16 * co + 4 * q + r) * P + pos] = old[co][r] + accx[co][r];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -970,6 +1039,19 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     const float* wl0[2] = {q.m1_w0, q.m2_w0}; const float* wl1[2] = {q.m1_w1, q.m2_w1};
     float* gw0[2] = {gq.m1_w0, gq.m2_w0}; float* gb0[2] = {gq.m1_b0, gq.m2_b0};
     float* gw1[2] = {gq.m1_w1, gq.m2_w1}; float* gb1[2] = {gq.m1_b1, gq.m2_b1};
+    static const bool m32_off = getenv("DPPM_DISABLE_LIN32") != nullptr;
+    if (!ws && H == 32 && !m32_off) {   // small networks: both MLP backward chains in one launch (dpre_1 -> dy, dpre_2 -> dmm, both free here)
+      DPPM_TRY(wgrad(c, H, dout[0], hs, H, hid[0], hs, gw1[0], H, gb1[0]));
+      DPPM_TRY(wgrad(c, H, dout[1], hs, H, hid[1], hs, gw1[1], H, gb1[1]));
+      const bool prof = prof_enabled();
+      if (prof) prof_before(c.st);
+      hipLaunchKernelGGL(mlp32_bwd_kernel, dim3(cdiv((long)B * cdiv(P, 16), 4)), dim3(256), 0, c.st, do1, do2, hid1, hid2, hs, wl1[0], wl1[1], wl0[0],
+                         wl0[1], dy, dmm, dx, dx_bs, P, B);
+      if (prof) prof_after(c.st, PROF_LINEAR, 8.0 * 32 * 32 * (double)P * B);
+      DPPM_TRY(check_launch("mlp32_bwd"));
+      DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gw0[0], H, gb0[0]));
+      DPPM_TRY(wgrad(c, H, dmm, hs, H, x, x_bs, gw0[1], H, gb0[1]));
+    } else
     for (int k = 0; k < 2; ++k) {
       DPPM_TRY(wgrad(c, H, dout[k], hs, H, hid[k], hs, gw1[k], H, gb1[k]));
       if (ws) {   // dpre = (W1^T dout) * act'(hid) ; dx += W0^T dpre, the intermediate never leaves the CU except as the saved copy
