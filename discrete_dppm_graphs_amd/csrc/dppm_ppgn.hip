@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
 // GEMM spends 11 us per launch on this shape (32 x 128 tile, K loop through LDS); 37 launches per training step.
 __global__ __launch_bounds__(256) void lin32t_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ X, long x_bs,
                                                      const float* __restrict__ dact, long dact_bs, float* __restrict__ Y, long y_bs,
-                                                     int P, int B, int accumulate) {
+                                                     int P, int B, int accumulate,
+                                                     const float* __restrict__ W2, float* __restrict__ Y2, long y2_bs, int accumulate2) {
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int ntile = (P + 15) >> 4;
   const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -470,6 +471,27 @@ __global__ __launch_bounds__(256) void lin32t_kernel(const float* __restrict__ W
         if (dact) v *= da[co][r] > 0.f ? 1.f : kSlope;
         yb[(size_t)(16 * co + 4 * q + r) * P + pos] = v + old[co][r];
       }
+  }
+  if (W2) {   // second job on the same source (the two halves of m4^T: d mm and d x from one read of dy); same pitch ldw
+    float* y2 = Y2 + (size_t)b * y2_bs;
+    floatx4 acc2[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}}, old2[2];
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) old2[co][r] = (accumulate2 && ok) ? y2[(size_t)(16 * co + 4 * q + r) * P + pos] : 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int co = 0; co < 2; ++co)
+          acc2[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(W2[(size_t)(16 * ci + 4 * q + r) * ldw + 16 * co + n], src[ci][r], acc2[co], 0, 0, 0);
+    if (ok) {
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y2[(size_t)(16 * co + 4 * q + r) * P + pos] = acc2[co][r] + old2[co][r];
+    }
   }
 }
 
@@ -610,7 +632,7 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
     hipLaunchKernelGGL(lin32t_kernel, dim3(cdiv((long)c.B * cdiv(c.P, 16), 4)), dim3(256), 0, c.st, s0.W, s0.ldw, s0.X, s0.x_bs, dact, dact_bs,
-                       Y, y_bs, c.P, c.B, accumulate ? 1 : 0);
+                       Y, y_bs, c.P, c.B, accumulate ? 1 : 0, (const float*)nullptr, (float*)nullptr, 0L, 0);
     if (prof) prof_after(c.st, PROF_LINEAR, 2.0 * 32 * 32 * (double)c.P * c.B);
     return check_launch("lin32t");
   }
@@ -1026,6 +1048,13 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       WsJob& j1 = wa.job[1];
       j1.X = dy; j1.x_bs = hs; j1.W1 = q.m4_w + H; j1.ldw1 = 2 * H; j1.Y = dx; j1.y_bs = dx_bs; j1.accumulate = l != 0;
       DPPM_TRY(ws_lin_p(wa, 1, true, prec, c.st));
+    } else if (H == 32 && getenv("DPPM_DISABLE_LIN32") == nullptr) {   // small networks: both halves of m4^T from one read of dy
+      const bool prof = prof_enabled();
+      if (prof) prof_before(c.st);
+      hipLaunchKernelGGL(lin32t_kernel, dim3(cdiv((long)B * cdiv(P, 16), 4)), dim3(256), 0, c.st, (const float*)q.m4_w, 2 * H, (const float*)dy, hs,
+                         (const float*)nullptr, 0L, dmm, hs, P, B, 0, (const float*)(q.m4_w + H), dx, dx_bs, l != 0 ? 1 : 0);
+      if (prof) prof_after(c.st, PROF_LINEAR, 4.0 * 32 * 32 * (double)P * B);
+      DPPM_TRY(check_launch("lin32t(m4^T)"));
     } else {
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dmm, hs, false));
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));
