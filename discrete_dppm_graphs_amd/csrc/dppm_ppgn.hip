@@ -30,7 +30,7 @@ struct Layout {
   size_t maskp, inv_norm, cat, u0, R, act, tmp[4];
   size_t hid1, hid2, o1, o2, mm;   // per-layer saves (training): base + l * S
   size_t rstd;                     // [L][B][H]
-  size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum;
+  size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to four 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
 };
@@ -80,6 +80,7 @@ Layout make_layout(int B, int N, int H, int L, int training) {
     if (H == WS_H && w.slab_floats < ws_wgrad_scratch_floats()) w.slab_floats = ws_wgrad_scratch_floats();
     w.slabs = bump(off, w.slab_floats);
     w.rsum = bump(off, (size_t)nz * H + (size_t)B * H + B);
+    w.w32 = H == 32 ? bump(off, (size_t)4 * nz * (1024 + 32)) : 0;
   }
   w.total = off;
   return w;
@@ -372,11 +373,10 @@ __global__ __launch_bounds__(RS_E * RS_G) void reduce_slabs_kernel(const float* 
 // take one 16 x 16 output tile each on v_mfma_f32_16x16x4_f32.  The generic split-K GEMM walks the same chunk in 16-position steps
 // of load -> LDS -> barrier -> MFMA on a 32 x 128 tile: 16.6 us per launch for this shape, 40 % of a small-network training step.
 constexpr int W32_MAXK = 512;
-__global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs,
-                                                      int P, int nsplit, int kchunk, float* __restrict__ slabs,
-                                                      float* __restrict__ rsum) {
+__device__ __forceinline__ void wgrad32_body(const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs,
+                                             int P, int nsplit, int kchunk, float* __restrict__ slabs, float* __restrict__ rsum, int z) {
   extern __shared__ __attribute__((aligned(16))) float w32_lds[];
-  const int z = blockIdx.x, b = z / nsplit, s = z % nsplit;
+  const int b = z / nsplit, s = z % nsplit;
   const int k0 = s * kchunk, kc = min(kchunk, P - k0);          // kchunk % 16 == 0, P % 4 == 0
   const int pitch = kchunk + 4;                                   // == 4 mod 16: fragment reads of 16 rows x 4 k are conflict-free
   float* sA = w32_lds;
@@ -423,6 +423,43 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
   if (do_rs && n == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) rsum[(size_t)z * 32 + m0 + 4 * q + r] = rs[r];
+  }
+}
+__global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ dY, long dy_bs, const float* __restrict__ X, long x_bs,
+                                                      int P, int nsplit, int kchunk, float* __restrict__ slabs,
+                                                      float* __restrict__ rsum) {
+  wgrad32_body(dY, dy_bs, X, x_bs, P, nsplit, kchunk, slabs, rsum, blockIdx.x);
+}
+
+// Up to four independent 32 x 32 weight gradients in one launch (a layer's m4 halves and second MLP matrices, or its two first MLP
+// matrices), and their slab reductions in one more: the per-matrix pairs of launches were 47 % of a small-network training step.
+constexpr int W32_MAXJOBS = 4;
+struct W32Job { const float* dY; long dy_bs; const float* X; long x_bs; float* dW; int ldo; float* db; };
+struct W32Args { W32Job job[W32_MAXJOBS]; int njobs, P, nsplit, kchunk, nz; float* slabs; float* rsum; };   // slabs [job][nz][1024], rsum [job][nz][32]
+__global__ __launch_bounds__(256) void wgrad32m_kernel(const W32Args a) {
+  const int j = blockIdx.x / a.nz, z = blockIdx.x - j * a.nz;
+  const W32Job& q = a.job[j];
+  wgrad32_body(q.dY, q.dy_bs, q.X, q.x_bs, a.P, a.nsplit, a.kchunk, a.slabs + (size_t)j * a.nz * 1024, a.rsum + (size_t)j * a.nz * 32, z);
+}
+// per job: 32 blocks fold dW (32 outputs each), one block folds db; fixed order as reduce_slabs_kernel
+__global__ __launch_bounds__(RS_E * RS_G) void reduce32m_kernel(const W32Args a) {
+  __shared__ float part[RS_G][RS_E];
+  const int j = blockIdx.x / 33, kind = blockIdx.x - j * 33;
+  const W32Job& q = a.job[j];
+  const bool bias = kind == 32;                                    // block-uniform
+  const int g = threadIdx.x / RS_E, t = threadIdx.x % RS_E;
+  const float* src = bias ? a.rsum + (size_t)j * a.nz * 32 : a.slabs + (size_t)j * a.nz * 1024;
+  const int MN = bias ? 32 : 1024, e = bias ? t : kind * RS_E + t;
+  float acc = 0.f;
+  for (int z = g; z < a.nz; z += RS_G) acc += src[(size_t)z * MN + e];
+  part[g][t] = acc;
+  __syncthreads();
+  if (g == 0) {
+    float v = part[0][t];
+#pragma unroll
+    for (int k = 1; k < RS_G; ++k) v += part[k][t];
+    if (bias) { if (q.db) q.db[e] = v; }
+    else q.dW[(size_t)(e >> 5) * q.ldo + (e & 31)] = v;
   }
 }
 
@@ -734,6 +771,36 @@ int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float*
   return wgrad_raw(Geo{c.w.B, c.w.P, c.st}, M, dY, dy_bs, Nw, X, x_bs, dW, ldo, db, c.at(c.w.slabs), c.w.slab_floats, c.at(c.w.rsum));
 }
 
+// several 32 x 32 weight gradients of the small networks in two launches (wgrad32m_kernel + reduce32m_kernel)
+bool wgrad32_multi_ok(const Ctx& c) {
+  static const bool off = getenv("DPPM_DISABLE_WGRAD32") != nullptr;
+  return !off && c.w.H == 32 && c.w.training && c.w.P % 4 == 0 && wgrad_kchunk(c.w.B, c.w.P) <= W32_MAXK;
+}
+int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
+  W32Args a{};
+  a.njobs = njobs; a.P = c.w.P; a.nsplit = wgrad_nsplit(c.w.B, c.w.P); a.kchunk = wgrad_kchunk(c.w.B, c.w.P); a.nz = c.w.B * a.nsplit;
+  a.slabs = c.at(c.w.w32); a.rsum = a.slabs + (size_t)W32_MAXJOBS * a.nz * 1024;
+  for (int j = 0; j < njobs; ++j) {
+    a.job[j] = jobs[j];
+    DPPM_REQUIRE(aligned16(jobs[j].dY) && aligned16(jobs[j].X) && jobs[j].dy_bs % 4 == 0 && jobs[j].x_bs % 4 == 0, "wgrad32_multi: unaligned operand");
+  }
+  const size_t lds = 2 * 32 * (size_t)(a.kchunk + 4) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad32m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(2 * 32 * (W32_MAXK + 4) * sizeof(float))) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "wgrad32_multi: cannot reserve LDS");
+    attr_done = true;
+  }
+  const bool prof = prof_enabled();
+  if (prof) prof_before(c.st);
+  hipLaunchKernelGGL(wgrad32m_kernel, dim3(njobs * a.nz), dim3(256), lds, c.st, a);
+  if (prof) prof_after(c.st, PROF_WGRAD, 2.0 * 32 * 32 * (double)c.w.P * c.w.B * njobs);
+  DPPM_TRY(check_launch("wgrad32m"));
+  hipLaunchKernelGGL(reduce32m_kernel, dim3(njobs * 33), dim3(RS_E * RS_G), 0, c.st, a);
+  return check_launch("reduce32m");
+}
+
 // per-plane products for all (b,c): C = op(A) * op(B) * inv_norm[b] (* mask[b])
 int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batch, int n, int ld, bool ta, bool tb,
              const float* scale, const float* mask, int div, int prec = DPPM_PREC_F32) {
@@ -1038,8 +1105,11 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
                      (const float*)maskp, (const float*)(c.at(w.rstd) + (size_t)l * B * H), dy, H, P);
     DPPM_TRY(check_launch("inorm_bwd"));
     // m4
-    DPPM_TRY(wgrad(c, H, dy, hs, H, mm, hs, gq.m4_w, 2 * H, gq.m4_b));
-    DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gq.m4_w + H, 2 * H, nullptr));
+    const bool multi = !ws && H == 32 && getenv("DPPM_DISABLE_LIN32") == nullptr && wgrad32_multi_ok(c);   // m4's gradients ride with the MLPs' below
+    if (!multi) {
+      DPPM_TRY(wgrad(c, H, dy, hs, H, mm, hs, gq.m4_w, 2 * H, gq.m4_b));
+      DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gq.m4_w + H, 2 * H, nullptr));
+    }
     if (ws) {
       WsArgs wa{};
       wa.njobs = 2; wa.B = B; wa.P = P;
@@ -1070,16 +1140,27 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     float* gw1[2] = {gq.m1_w1, gq.m2_w1}; float* gb1[2] = {gq.m1_b1, gq.m2_b1};
     static const bool m32_off = getenv("DPPM_DISABLE_LIN32") != nullptr;
     if (!ws && H == 32 && !m32_off) {   // small networks: both MLP backward chains in one launch (dpre_1 -> dy, dpre_2 -> dmm, both free here)
-      DPPM_TRY(wgrad(c, H, dout[0], hs, H, hid[0], hs, gw1[0], H, gb1[0]));
-      DPPM_TRY(wgrad(c, H, dout[1], hs, H, hid[1], hs, gw1[1], H, gb1[1]));
+      if (multi) {   // dy is still m4's output gradient here: four weight gradients in one launch, before dy is reused for dpre_1
+        const W32Job jobs[4] = {{dy, hs, mm, hs, gq.m4_w, 2 * H, gq.m4_b}, {dy, hs, x, x_bs, gq.m4_w + H, 2 * H, nullptr},
+                                {dout[0], hs, hid[0], hs, gw1[0], H, gb1[0]}, {dout[1], hs, hid[1], hs, gw1[1], H, gb1[1]}};
+        DPPM_TRY(wgrad32_multi(c, jobs, 4));
+      } else {
+        DPPM_TRY(wgrad(c, H, dout[0], hs, H, hid[0], hs, gw1[0], H, gb1[0]));
+        DPPM_TRY(wgrad(c, H, dout[1], hs, H, hid[1], hs, gw1[1], H, gb1[1]));
+      }
       const bool prof = prof_enabled();
       if (prof) prof_before(c.st);
       hipLaunchKernelGGL(mlp32_bwd_kernel, dim3(cdiv((long)B * cdiv(P, 16), 4)), dim3(256), 0, c.st, do1, do2, hid1, hid2, hs, wl1[0], wl1[1], wl0[0],
                          wl0[1], dy, dmm, dx, dx_bs, P, B);
       if (prof) prof_after(c.st, PROF_LINEAR, 8.0 * 32 * 32 * (double)P * B);
       DPPM_TRY(check_launch("mlp32_bwd"));
-      DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gw0[0], H, gb0[0]));
-      DPPM_TRY(wgrad(c, H, dmm, hs, H, x, x_bs, gw0[1], H, gb0[1]));
+      if (multi) {
+        const W32Job jobs[2] = {{dy, hs, x, x_bs, gw0[0], H, gb0[0]}, {dmm, hs, x, x_bs, gw0[1], H, gb0[1]}};
+        DPPM_TRY(wgrad32_multi(c, jobs, 2));
+      } else {
+        DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gw0[0], H, gb0[0]));
+        DPPM_TRY(wgrad(c, H, dmm, hs, H, x, x_bs, gw0[1], H, gb0[1]));
+      }
     } else
     for (int k = 0; k < 2; ++k) {
       DPPM_TRY(wgrad(c, H, dout[k], hs, H, hid[k], hs, gw1[k], H, gb1[k]));
