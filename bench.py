@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the discrete graph-DDPM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[3], the configuration the metric is quoted on): synthetic SBM graphs with N = 200 nodes,
-the 8 x 128 PPGN of gridsearch_ppgn_simple.py:19, `ppgn_simple` sampling with 64 noise levels, 32 graphs per GPU.
+N > 1 without a torch.distributed environment: this process makes no GPU call, starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`),
+relays rank 0's JSON line and exits with the launcher's status.  Under torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE set) it is one rank of the job.
+
+Workload (default = BASELINE.json configs[3], the configuration the metric is quoted on): synthetic SBM graphs with N = 200
+nodes, the 8 x 128 PPGN of gridsearch_ppgn_simple.py:19, `ppgn_simple` sampling with 64 noise levels, 32 graphs per GPU.
 One step = one full reverse chain (x_T init, then 64 x [re-noise, denoiser forward, reverse step]) over one batch; graphs
 are independent, so ranks take disjoint graph ids and exchange nothing (weak scaling).  `value` = graphs finished per
-second over all ranks.  The sampler's denoiser runs in `--precision` (default bf16x3: float32 tensors, H=128 matrix
-products as three bf16 MFMAs on split operands with float32 accumulation, held to the float32 parity bar by
-tests/test_gpu_ppgn.py); `exact_f32` carries the same chain with exact-float32 MFMAs for comparison.  The same line also carries the training throughput (optimizer steps/s at global batch
-32 x N GPUs, data parallel with one flat-gradient all-reduce per step), the roofline of the dominant kernel measured
-live with HIP events, and a CPU baseline (the oracle's torch-CPU restatement on the host cores, bounded sample).
+second over all ranks, denoiser in `--precision` (default bf16x3: float32 tensors, H = 128 matrix products as three bf16
+MFMAs on split operands with float32 accumulation, held to the float32 parity bar by tests/test_gpu_ppgn.py).  `exact_f32`
+carries the same chains over the same number of steps with exact-float32 MFMAs and its own roofline object.  The line also
+carries the training throughput (optimizer steps/s at global batch 32 x N GPUs, data parallel with one flat-gradient
+all-reduce per step), a per-kernel-class table measured live with HIP events on the launch stream, and the CPU baseline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +36,22 @@ if ROOT not in sys.path:
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # idem, dense bf16
 HBM_PEAK_GBS = 8000.0
+
+# kernel classes of dppm_prof_end (include/dppm_hip.h) -> what runs in them, per precision mode
+KERNEL_NAMES = {
+    "wstat_mlp2": {"split": "w3_mlp_kernel (both per-position MLPs of a PPGN layer, model/ppgn.py:58-59; float32 in HBM, operands split into "
+                            "bf16 pieces in LDS, v_mfma_f32_16x16x32_bf16; reads X, writes o1 and o2)",
+                   "f32": "ws_mlp_kernel (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32, 8*H^2*P*B FLOP per launch)"},
+    "wstat_sum2": {"split": "w3_lin2_kernel (skip-concat Linear m4, model/ppgn.py:66-69; layer_cat_lin two layer outputs at a time, :318,327)",
+                   "f32": "ws_lin_kernel<2> (skip-concat Linear m4 and the layer_cat_lin pairs, v_mfma_f32_16x16x4_f32)"},
+    "wstat_cols": {"split": "w3_lin_kernel<.,1> (after_conv, model/ppgn.py:331)", "f32": "ws_lin_kernel<1> (after_conv; transposed data-gradient forms)"},
+    "plane_matmul": {"split": "plane3_kernel (per-channel N x N contraction, model/ppgn.py:62; split-bf16 operands on v_mfma_f32_16x16x32_bf16)",
+                     "f32": "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)"},
+    "inorm": {"split": "inorm_fwd_kernel (masked instance norm, util/model_helper.py:176-191)", "f32": "inorm_fwd_kernel / inorm_bwd_kernel"},
+    "linear_gemm": {"split": "gemm_f32_kernel (per-position linears of networks with H != 128)", "f32": "gemm_f32_kernel (per-position linears, H != 128)"},
+    "wgrad_gemm": {"split": "ws6_wgrad_kernel", "f32": "ws6_wgrad_kernel (weight gradients, three-piece bf16 split) / generic split-K GEMM"},
+    "head": {"split": "head3_kernel (layer_cat_lin + after_conv + final_lin in one pass, model/ppgn.py:318-333)", "f32": "-"},
+}
 
 
 def sbm_graphs(rng, B, N, p_intra=0.3, p_inter=0.005):
@@ -50,29 +73,139 @@ def fwd_flops_per_graph(N, H, L):
     return 4 * N * N * H + L * (12 * N * N * H * H + 2 * H * N ** 3) + 2 * N * N * H * (L * H + 2) + 2 * N * N * H * H + 2 * N * N * H
 
 
-def cpu_baseline(N, H, L, T, seconds_budget=20.0):
-    """The oracle (oracle/ppgn.py + oracle/diffusion.py, torch CPU fp32) on a bounded sample of the same workload:
-    2 graphs through as many chain steps as fit the budget (>= 2), extrapolated to the full T-step chain."""
+# --------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_leg(N, H, L, T, Bc, faithful, threads, budget_s, max_steps=4):
+    """Time chain steps of the oracle's sampler on `threads` host threads.  faithful: the mask is rebuilt every step with the
+    reference's Python triple loop (utils/graph_utils.py:312-319, called from take_step at sample_ppgn_simple.py:56) and the
+    p = 1/2 matrix of gen_init_data with its Python loop (:32-37, once per chain, amortised over the T steps); otherwise the
+    vectorised restatement.  One warm-up step, then the median of up to `max_steps` (>= 3) timed steps."""
     from oracle import diffusion as od, ppgn as op
-    rng = np.random.default_rng(1234)
-    Bc = 2
-    A = sbm_graphs(rng, Bc, N)
-    flags = (A.sum(-1) > 1e-5).astype(np.float32)
-    mask = od.generate_mask(flags)
-    W = op.init_weights(L, H, seed=1234)
-    x = od.gen_init_data(flags, rng.random((Bc, N, N), dtype=np.float32))
-    sig = od.schedule_simple(T)
-    steps, t0 = 0, time.perf_counter()
-    with torch.no_grad():
-        while steps < 2 or (time.perf_counter() - t0 < seconds_budget and steps < T):
-            s = sig[len(sig) - steps - 1]
-            x, _ = od.take_step_simple(x, lambda a: op.powerful_forward(W, a, mask, s, L).squeeze(-1), flags, s,
-                                       rng.random((Bc, N, N), dtype=np.float32), rng.random((Bc, N, N), dtype=np.float32))
-            steps += 1
-    dt = time.perf_counter() - t0
-    per_graph_chain = dt / steps * T / Bc
-    return {"value": 1.0 / per_graph_chain, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{Bc} graphs x {steps} of {T} chain steps (N={N}, {L}x{H} PPGN, torch CPU fp32 oracle), extrapolated to the full chain"}
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        rng = np.random.default_rng(1234)
+        A = sbm_graphs(rng, Bc, N)
+        flags = (A.sum(-1) > 1e-5).astype(np.float32)
+        W = op.init_weights(L, H, seed=1234)
+        t_init = 0.0
+        if faithful:
+            t0 = time.perf_counter()
+            od.gen_init_prob_loop(flags)
+            t_init = time.perf_counter() - t0
+        x = od.gen_init_data(flags, rng.random((Bc, N, N), dtype=np.float32))
+        sig = od.schedule_simple(T)
+        times = []
+        t_begin = time.perf_counter()
+        with torch.no_grad():
+            for c in range(1 + max_steps):
+                s = sig[len(sig) - c - 1]
+                t0 = time.perf_counter()
+                mask = od.generate_mask_loop(flags) if faithful else od.generate_mask(flags)
+                x, _ = od.take_step_simple(x, lambda a: op.powerful_forward(W, a, mask, s, L).squeeze(-1), flags, s,
+                                           rng.random((Bc, N, N), dtype=np.float32), rng.random((Bc, N, N), dtype=np.float32))
+                if c > 0:
+                    times.append(time.perf_counter() - t0)
+                if len(times) >= 3 and time.perf_counter() - t_begin > budget_s:
+                    break
+        step = float(np.median(times))
+        per_graph_chain = (step * T + t_init) / Bc
+        return {"graphs_per_s": 1.0 / per_graph_chain, "s_per_chain_step": step, "graphs": Bc, "timed_steps": len(times), "threads": threads}
+    finally:
+        torch.set_num_threads(old)
+
+
+def cpu_baseline(N, H, L, T):
+    """The oracle (oracle/ppgn.py + oracle/diffusion.py, torch CPU fp32) on a bounded sample of the same workload (SURVEY.md
+    section 8d): the reference-faithful form (whole-batch forward as the reference's sampler calls it, mask and p = 1/2 matrix
+    built by the reference's Python loops) and the batched restatement (vectorised mask), each on 1 thread and on all the
+    threads torch uses on this host; extrapolated from a few chain steps to the full T-step chain."""
+    k_all = torch.get_num_threads()
+    big = N >= 100
+    Bc = 1 if big else 4
+    legs = {}
+    for name, faithful in (("reference_faithful", True), ("batched_restatement", False)):
+        for k in sorted({1, k_all}):
+            legs[f"{name}_k{k}"] = _cpu_leg(N, H, L, T, Bc, faithful, k, budget_s=8.0 if big else 4.0)
+    best = legs[f"reference_faithful_k{k_all}"]
+    return {"value": best["graphs_per_s"], "unit": "graphs/s", "cores": k_all, "kind": "port",
+            "sample": f"{Bc} graph(s) x 1 warm-up + {best['timed_steps']} timed chain steps of {T} (median), N={N}, {L}x{H} PPGN, oracle "
+                      f"(torch CPU fp32) in the reference-faithful form on {k_all} threads, extrapolated to the full chain",
+            "legs": legs}
+
+
+# --------------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Parent of an N-rank run: no GPU call is made here."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                 # relay; the one JSON line of rank 0 is re-printed last, alone
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------- roofline objects
+def kernel_table(prof, mode, dt, traffic_json):
+    """Per kernel class: launches, average launch time, share of the timed region and its roofline against the roof that
+    bounds it.  Split-bf16 kernels (and the instance norm in every mode) are HBM-bound: achieved = algorithmic bytes per launch
+    (every distinct operand read once, every result written once, counted by the library per launch) / average launch time,
+    against 8 TB/s; their matrix work is also shown as a fraction of the dense bf16 MFMA peak (3 MFMAs per product in bf16x3, 1
+    in bf16).  Exact-f32 kernels are bound by the f32 MFMA pipe: algorithmic FLOP/s against 157.3 TFLOP/s."""
+    nterm = {"bf16x3": 3, "bf16": 1}.get(mode, 0)
+    table = {}
+    for k, c in prof.items():
+        if c["launches"] == 0:
+            continue
+        avg_ms = c["ms"] / c["launches"]
+        is_norm = k == "inorm"
+        flops = 0.0 if is_norm else c["work"]
+        tfl = flops / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
+        gbs = c["bytes"] / (c["ms"] * 1e-3) / 1e9 if c["ms"] > 0 else 0.0
+        hbm_bound = is_norm or (nterm > 0 and k in ("wstat_mlp2", "wstat_sum2", "wstat_cols", "plane_matmul", "head"))
+        e = {"kernel": KERNEL_NAMES.get(k, {}).get("split" if nterm and not is_norm else "f32", k), "launches": c["launches"],
+             "avg_launch_ms": avg_ms, "share_of_step_time": c["ms"] * 1e-3 / dt,
+             "bytes_per_launch": c["bytes"] / c["launches"], "flops_per_launch": flops / c["launches"]}
+        if hbm_bound:
+            e.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+            if not is_norm:
+                e["f32_equivalent_tflops"] = tfl
+                e["bf16_mfma_frac"] = nterm * tfl / BF16_MFMA_PEAK_TFLOPS
+        else:
+            e.update({"bound": "mfma", "achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MFMA_PEAK_TFLOPS,
+                      "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+        e["traffic"] = (traffic_json or {}).get(k)
+        table[k] = e
+    return table
+
+
+def dominant(table):
+    """The kernel class with the largest summed device time in the timed region."""
+    if not table:
+        return None
+    k = max(table, key=lambda n: table[n]["share_of_step_time"])
+    e = dict(table[k])
+    e["class"] = k
+    return e
 
 
 def main():
@@ -87,21 +220,38 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="graphs per GPU")
     ap.add_argument("--train-steps", type=int, default=3, help="timed optimizer steps for the training figure (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-float32 comparison chain")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-float32 comparison chains")
     ap.add_argument("--no-prof", action="store_true",
                     help="no per-kernel HIP events in the timed region (the roofline objects are then empty): for the launch-bound "
                          "small configurations, where two event records per kernel are a visible share of a 9 us launch")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="matrix arithmetic of the sampler's H=128 kernels (include/dppm_hip.h DPPM_PREC_*)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="rendezvous only (gloo, no GPU call): checks that --gpus N starts N ranks and relays rank 0's line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: drop the torch.distributed environment (bench.py starts its own "
+                         f"ranks) or launch with --nproc-per-node {args.gpus}")
     import torch.distributed as dist
+    if args.selftest_launch:
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1.0])
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "selftest", "value": float(t.item()), "n_gpus": world}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -124,37 +274,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ------------------------------------------------------------------ sampling (headline)
-    for w in range(args.warmup):
-        engine.sample_chain_simple(model, flags, T, seed + w, gid0)
-    barrier()
-    if not args.no_prof:
-        ops.prof_begin()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        out = engine.sample_chain_simple(model, flags, T, seed + 100 + k, gid0 + k * world * B)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof, truncated = ops.prof_end() if not args.no_prof else ({k: {"ms": 0.0, "work": 0.0, "launches": 0} for k in ops.PROF_CLASSES}, False)
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    assert out.shape == (B, N, N) and torch.equal(out, out.transpose(1, 2))
-    graphs_per_s = args.steps * B * world / dt
+    def max_over_ranks(x):
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # the same chain with exact-float32 matrix products (one warm-up chain, one timed), rank 0's clock
+    empty_prof = {k: {"ms": 0.0, "work": 0.0, "bytes": 0.0, "launches": 0} for k in ops.PROF_CLASSES}
+
+    def timed_chains(steps, warmup):
+        for w in range(warmup):
+            engine.sample_chain_simple(model, flags, T, seed + w, gid0)
+        barrier()
+        if not args.no_prof:
+            ops.prof_begin()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            out = engine.sample_chain_simple(model, flags, T, seed + 100 + k, gid0 + k * world * B)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof, truncated = ops.prof_end() if not args.no_prof else (empty_prof, False)
+        assert out.shape == (B, N, N) and torch.equal(out, out.transpose(1, 2))
+        return max_over_ranks(dt), prof, truncated
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_aggregate.py from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("geometry") == {"nodes": N, "hidden": H, "layers": L, "graphs_per_gpu": B} and tj.get("precision", "bf16x3") == args.precision:
+            traffic = tj.get("bytes_per_launch")
+
+    # ------------------------------------------------------------------ sampling (headline)
+    dt, prof, truncated = timed_chains(args.steps, args.warmup)
+    graphs_per_s = args.steps * B * world / dt
+    table = kernel_table(prof, args.precision, dt, traffic)
+
+    # the same chains with exact-float32 matrix products: same number of steps, its own kernel table
     exact = None
     if args.precision != "f32" and not args.no_exact_f32:
         model.precision = "f32"
-        engine.sample_chain_simple(model, flags, T, seed, gid0)
-        barrier()
-        t0 = time.perf_counter()
-        engine.sample_chain_simple(model, flags, T, seed + 100, gid0)
-        barrier()
-        edt = time.perf_counter() - t0
-        exact = {"value": B * world / edt, "unit": "graphs/s", "ms_per_step": 1e3 * edt, "steps": 1,
-                 "note": "same workload with DPPM_PREC_F32 (v_mfma_f32_16x16x4_f32) in every kernel"}
+        edt, eprof, _ = timed_chains(args.steps, 1)
+        etable = kernel_table(eprof, "f32", edt, None)
+        exact = {"value": args.steps * B * world / edt, "unit": "graphs/s", "ms_per_step": 1e3 * edt / args.steps, "steps": args.steps,
+                 "dtype": "f32", "note": "same workload with DPPM_PREC_F32 (v_mfma_f32_16x16x4_f32) in every kernel",
+                 "model_tflops": args.steps * B * world / edt * T * fwd_flops_per_graph(N, H, L) / 1e12,
+                 "roofline": dominant(etable), "kernels": etable}
         model.precision = args.precision
 
     # ------------------------------------------------------------------ training throughput (second half of the metric)
@@ -163,109 +327,54 @@ def main():
         model.train()
         state = engine.FlatState(model, lr=1e-3)
         adj = torch.as_tensor(sbm_graphs(rng, B, N)).cuda()
-        sig = lambda: np.random.default_rng(99).uniform(0.0, 0.5, size=B)
-        loss = engine.train_step_simple(model, state, adj, sig(), seed, 0, gid0, B_global=B * world)
+        sig = torch.as_tensor(np.random.default_rng(99).uniform(0.0, 0.5, size=B)).cuda()      # resident draws, as fit() keeps them
+        loss = engine.train_step_simple(model, state, adj, sig, seed, 0, gid0, B_global=B * world)
         barrier()
         if not args.no_prof:
             ops.prof_begin()
         t0 = time.perf_counter()
         for k in range(args.train_steps):
-            loss = engine.train_step_simple(model, state, adj, sig(), seed, 1 + k, gid0, B_global=B * world)
+            loss = engine.train_step_simple(model, state, adj, sig, seed, 1 + k, gid0, B_global=B * world)
         barrier()
         tdt = time.perf_counter() - t0
-        tprof = ops.prof_end()[0] if not args.no_prof else {}
-        tm = torch.tensor([tdt], device="cuda", dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        tdt = float(tm.item())
+        tprof = ops.prof_end()[0] if not args.no_prof else empty_prof
+        tdt = max_over_ranks(tdt)
         F = fwd_flops_per_graph(N, H, L)
+        ttable = kernel_table(tprof, "f32", tdt, None)
         train = {"train_steps_per_s": args.train_steps / tdt, "ms_per_train_step": 1e3 * tdt / args.train_steps,
-                 "global_batch": B * world, "loss": float(loss.item()),
+                 "global_batch": B * world, "loss": float(loss.item()), "dtype": "f32",
                  "model_tflops": 3 * F * B * world * args.train_steps / tdt / 1e12,
-                 "kernel_classes": {k: {"ms_per_step": v["ms"] / args.train_steps,
-                                        "tflops": (v["work"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and k != "inorm" else None}
-                                    for k, v in tprof.items()}}
+                 "roofline": dominant(ttable), "kernels": ttable}
         model.eval()
 
     if rank == 0:
-        pmm, nrm = prof["plane_matmul"], prof["inorm"]
-        lin_keys = ("linear_gemm", "wstat_mlp2", "wstat_sum2", "wstat_cols")
-        lin = {f: sum(prof[k][f] for k in lin_keys) for f in ("ms", "work", "launches")}
-        tf = lambda c: (c["work"] / (c["ms"] * 1e-3) / 1e12) if c["ms"] > 0 else 0.0
-        # dominant kernel: the fused MLP pair when H = 128 (weight-stationary path), else the generic linear GEMM
-        dom_key = "wstat_mlp2" if prof["wstat_mlp2"]["launches"] > 0 else "linear_gemm"
-        dom = prof[dom_key]
-        split = args.precision != "f32" and dom_key == "wstat_mlp2"
-        dom_name = {"wstat_mlp2": "ws_mlp_kernel<false,false,false> (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32; "
-                                  "8*H^2*P*B FLOP per launch)",
-                    "linear_gemm": "gemm_f32_kernel<...,TAG=0> (per-position linear layers, v_mfma_f32_32x32x2_f32)"}[dom_key]
-        if split:
-            dom_name = ("w3_mlp_kernel<%d,%d> (both per-position MLPs of a PPGN layer; float32 in HBM, operands split into bf16 pieces in "
-                        "LDS, v_mfma_f32_16x16x32_bf16; algorithmic traffic 3*B*H*P*4 bytes per launch: read X, write o1 and o2)"
-                        % ((3, 1) if args.precision == "bf16x3" else (1, 2)))
         F = fwd_flops_per_graph(N, H, L)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by tools/pmc_aggregate.py from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("geometry") == {"nodes": N, "hidden": H, "layers": L, "graphs_per_gpu": B}:
-                traffic = tj.get("bytes_per_launch", {}).get(dom_key)
-        avg_ms = dom["ms"] / max(dom["launches"], 1)
-        common = {"traffic": traffic, "launches": dom["launches"], "avg_launch_ms": avg_ms,
-                  "flops_per_launch": dom["work"] / max(dom["launches"], 1), "share_of_step_time": dom["ms"] * 1e-3 / dt,
-                  "records_truncated": truncated}
-        if split:     # HBM-bound: 3 plane sets of B*H*P floats per launch (P = N * round_up(N, 4))
-            alg_bytes = 3.0 * B * H * N * ((N + 3) // 4 * 4) * 4
-            gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            nterm = 3 if args.precision == "bf16x3" else 1
-            roofline = {"kernel": dom_name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "bytes_per_launch": alg_bytes, "f32_equivalent_tflops": tf(dom),
-                        "bf16_mfma_frac": nterm * tf(dom) / BF16_MFMA_PEAK_TFLOPS, **common}
-        else:
-            roofline = {"kernel": dom_name, "bound": "mfma", "achieved": tf(dom), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf(dom) / F32_MFMA_PEAK_TFLOPS, **common}
-        mm_hbm = None
-        if split and pmm["ms"] > 0:
-            mm_bytes = 3.0 * B * H * N * ((N + 3) // 4 * 4) * 4 * pmm["launches"]
-            mm_hbm = {"achieved": mm_bytes / (pmm["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": mm_bytes / (pmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        roofline = dominant(table)
+        if roofline is not None:
+            roofline["records_truncated"] = truncated
+        cfg_names = {(200, 128, 8): "BASELINE configs[3] geometry", (512, 128, 8): "BASELINE configs[4] geometry",
+                     (60, 128, 8): "BASELINE configs[2] geometry (sampling)", (20, 32, 6): "BASELINE configs[1] geometry",
+                     (18, 32, 6): "BASELINE configs[0] geometry"}
         line = {
-            "metric": "graphs sampled/s (PPGN, N=200); train steps/s in `train`", "value": graphs_per_s, "unit": "graphs/s",
+            "metric": f"graphs sampled/s (PPGN, N={N}); train steps/s in `train`", "value": graphs_per_s, "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 (tensors float32; H=128 products on bf16x3-split MFMA, float32 accumulate, 1e-3 parity bar held)",
                       "bf16": "bf16 products, float32 tensors and accumulation"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"ppgn_simple sampling on synthetic SBM N={N} (BASELINE configs[3]): {L}x{H} PPGN, "
+            "config": {"workload": f"ppgn_simple sampling on synthetic SBM N={N} ({cfg_names.get((N, H, L), 'custom geometry')}): {L}x{H} PPGN, "
                                    f"{T} noise levels, {B} graphs/GPU per chain", "nodes": N, "hidden": H, "layers": L,
-                       "noise_levels": T, "graphs_per_gpu": B, "parallelism": f"graph-sharded x{world}, no collective"},
+                       "noise_levels": T, "graphs_per_gpu": B, "precision": args.precision,
+                       "parallelism": f"graph-sharded x{world}, no collective"},
             "model_tflops": graphs_per_s * T * F / 1e12,
             "roofline": roofline,
-            "roofline_linear_all": {"kernel": "every per-position linear layer (w3_mlp_kernel, w3_lin2_kernel, w3_lin_kernel in the split modes; "
-                                              "ws_mlp_kernel, ws_lin_kernel<2>, ws_lin_kernel<1> in f32; generic GEMM when H != 128)",
-                                    "bound": "hbm (f32-equivalent TFLOP/s shown against the f32 MFMA peak it would need)" if split else "mfma",
-                                    "achieved": tf(lin), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": tf(lin) / F32_MFMA_PEAK_TFLOPS, "share_of_step_time": lin["ms"] * 1e-3 / dt,
-                                    "by_kernel": {k: {"tflops": tf(prof[k]), "launches": prof[k]["launches"],
-                                                      "avg_launch_ms": prof[k]["ms"] / max(prof[k]["launches"], 1)} for k in lin_keys}},
-            "roofline_matmul": {"kernel": ("plane3_kernel (per-channel N x N contraction, split-bf16 operands on v_mfma_f32_16x16x32_bf16, model/ppgn.py:62)"
-                                           if split else
-                                           "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)"),
-                                "bound": "mfma", "achieved": tf(pmm), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tf(pmm) / F32_MFMA_PEAK_TFLOPS, "hbm": mm_hbm,
-                                "launches": pmm["launches"], "avg_launch_ms": pmm["ms"] / max(pmm["launches"], 1),
-                                "share_of_step_time": pmm["ms"] * 1e-3 / dt},
-            "roofline_inorm": {"bound": "hbm", "achieved": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9) if nrm["ms"] > 0 else 0.0,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": (nrm["work"] / (nrm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if nrm["ms"] > 0 else 0.0,
-                               "avg_launch_ms": nrm["ms"] / max(nrm["launches"], 1),
-                               "share_of_step_time": nrm["ms"] * 1e-3 / dt},
+            "kernels": table,
             "exact_f32": exact,
             "train": train,
         }
         if not args.no_cpu_baseline and world == 1:     # the host-core baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(N, H, L, T)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

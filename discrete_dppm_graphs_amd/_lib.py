@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdppm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # DPPM_PREC_* of include/dppm_hip.h
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
@@ -71,8 +71,9 @@ SIGNATURES = {
     "dppm_mmd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dppm_mmd_gaussian_emd": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_double, C.c_double, c_f64p, C.c_void_p,
                                         C.c_size_t, c_stream]),
+    "dppm_test_fill_lds": (C.c_int, [C.c_uint32, c_stream]),
     "dppm_prof_begin": (C.c_int, [C.c_int]),
-    "dppm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
+    "dppm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
     "dppm_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int, C.c_float, c_stream]),
 }

@@ -41,7 +41,7 @@ enum ProfClass { PROF_LINEAR = 0, PROF_PLANE_MM = 1, PROF_WGRAD = 2, PROF_NORM =
                  PROF_WS_MLP2 = 4, PROF_WS_SUM2 = 5, PROF_WS_COLS = 6, PROF_NCLASS = 7 };
 bool prof_enabled();
 void prof_before(hipStream_t st);
-void prof_after(hipStream_t st, int cls, double work);
+void prof_after(hipStream_t st, int cls, double work, double bytes = 0.0);   // work: algorithmic FLOPs, bytes: algorithmic HBM bytes of the launch
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

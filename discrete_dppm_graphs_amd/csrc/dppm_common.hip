@@ -8,7 +8,7 @@ char* error_buffer() {
 }
 
 namespace {
-struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
+struct ProfRec { hipEvent_t e0, e1; int cls; double work, bytes; };
 struct ProfState {
   bool on = false;
   std::vector<ProfRec> recs;
@@ -23,11 +23,12 @@ void prof_before(hipStream_t st) {
   if (!g_prof.on || g_prof.used >= g_prof.recs.size()) return;
   (void)hipEventRecord(g_prof.recs[g_prof.used].e0, st);
 }
-void prof_after(hipStream_t st, int cls, double work) {
+void prof_after(hipStream_t st, int cls, double work, double bytes) {
   if (!g_prof.on || g_prof.used >= g_prof.recs.size()) return;
   ProfRec& r = g_prof.recs[g_prof.used++];
   r.cls = cls;
   r.work = work;
+  r.bytes = bytes;
   (void)hipEventRecord(r.e1, st);
 }
 }  // namespace dppm
@@ -46,12 +47,12 @@ extern "C" int dppm_prof_begin(int max_records) {
   return DPPM_OK;
 }
 
-extern "C" int dppm_prof_end(double* ms_per_class, double* work_per_class, long* launches_per_class, int nclass) {
+extern "C" int dppm_prof_end(double* ms_per_class, double* work_per_class, double* bytes_per_class, long* launches_per_class, int nclass) {
   using namespace dppm;
   g_prof.on = false;
-  if (!ms_per_class || !work_per_class || !launches_per_class || nclass < PROF_NCLASS)
+  if (!ms_per_class || !work_per_class || !bytes_per_class || !launches_per_class || nclass < PROF_NCLASS)
     return fail(DPPM_E_INVALID, "dppm_prof_end: need %d classes", (int)PROF_NCLASS);
-  for (int c = 0; c < nclass; ++c) { ms_per_class[c] = 0; work_per_class[c] = 0; launches_per_class[c] = 0; }
+  for (int c = 0; c < nclass; ++c) { ms_per_class[c] = 0; work_per_class[c] = 0; bytes_per_class[c] = 0; launches_per_class[c] = 0; }
   for (size_t i = 0; i < g_prof.used; ++i) {
     ProfRec& r = g_prof.recs[i];
     if (hipEventSynchronize(r.e1) != hipSuccess) return fail(DPPM_E_LAUNCH, "dppm_prof_end: event sync failed");
@@ -59,6 +60,7 @@ extern "C" int dppm_prof_end(double* ms_per_class, double* work_per_class, long*
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(DPPM_E_LAUNCH, "dppm_prof_end: elapsed failed");
     ms_per_class[r.cls] += ms;
     work_per_class[r.cls] += r.work;
+    bytes_per_class[r.cls] += r.bytes;
     launches_per_class[r.cls] += 1;
   }
   const int dropped = (int)(g_prof.used >= g_prof.recs.size());
@@ -67,4 +69,4 @@ extern "C" int dppm_prof_end(double* ms_per_class, double* work_per_class, long*
 }
 
 extern "C" const char* dppm_last_error(void) { return dppm::error_buffer(); }
-extern "C" int dppm_abi_version(void) { return 2; }
+extern "C" int dppm_abi_version(void) { return 3; }

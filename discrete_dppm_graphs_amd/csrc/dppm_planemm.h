@@ -377,7 +377,7 @@ inline int plane_mm_launch(const PlaneArgs& a, int batch, bool a_kmajor, bool b_
 #undef DPPM_PLANE16_CASE
     default: rc = fail(DPPM_E_UNSUPPORTED, "plane_mm: n=%d exceeds the strip kernel's range", a.n);
   }
-  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch);
+  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
   return rc;
 }
 

@@ -240,7 +240,7 @@ inline int plane3_launch(const PlaneArgs& a, int batch, hipStream_t st) {
     case 16: rc = plane3_launch_nt<16, NS>(a, batch, 1, st); break;
     default: rc = fail(DPPM_E_UNSUPPORTED, "plane3: n=%d outside 129..1024", a.n);
   }
-  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch);
+  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
   return rc;
 }
 

@@ -981,7 +981,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     if (prof_enabled()) prof_before(c.st);
     launch_inorm_fwd(P, B * H, c.st, (const float*)y, hs, (const float*)maskp, cat + (size_t)(2 + l * H) * P, cat_bs, H, P, (float*)nullptr,
                      c.at(w.rstd) + (size_t)l * B * H);
-    if (prof_enabled()) prof_after(c.st, PROF_NORM, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
+    if (prof_enabled()) prof_after(c.st, PROF_NORM, 2.0 * sizeof(float) * (double)w.S, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
     DPPM_TRY(check_launch("inorm_fwd"));
   }
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)

@@ -334,7 +334,10 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
         const float* pb = O2 + (SG_CPW * w + c) * SG_PITCH;
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
-          const bool live = 4 * ks < ld;
+          // k < N only: rows N .. ld-1 of an o2 plane lie beyond the last position the MLP phase writes when N % 4 != 0
+          // (positions >= 16 * ceil(P / 16)), i.e. LDS that nobody initialised; the matching o1 column is an exact zero, but
+          // 0 * (stale Inf / NaN bit pattern) would be NaN, so those k steps are forced to zero on both sides
+          const bool live = 4 * ks + q < N;
           const int k = live ? 4 * ks + q : q;
           const float va0 = pa[i0 * ld + k], vb0 = pb[k * ld + j0];
           fa0[ks] = live ? va0 : 0.f; fb0[ks] = live ? vb0 : 0.f;
@@ -525,7 +528,29 @@ int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, co
   return check_launch("sg_forward");
 }
 
+// test hook: every workgroup fills all of its CU's allocatable LDS with `pattern` (tests/test_gpu_smallgraph.py poisons the
+// LDS with NaN bit patterns before sg_forward to show that no uninitialised word reaches a result)
+__global__ __launch_bounds__(256) void lds_fill_kernel(unsigned pattern, unsigned nwords, unsigned* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned fill_lds[];
+  for (unsigned i = threadIdx.x; i < nwords; i += 256) fill_lds[i] = pattern;
+  __syncthreads();
+  if (sink && fill_lds[(threadIdx.x * 97u) % nwords] != pattern) sink[0] = 1u;   // keeps the stores alive
+}
+
 }  // namespace dppm
+
+extern "C" int dppm_test_fill_lds(uint32_t pattern, void* stream) {
+  using namespace dppm;
+  const size_t bytes = 160 * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "dppm_test_fill_lds: cannot reserve %zu bytes of LDS", bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(lds_fill_kernel, dim3(2048), dim3(256), bytes, as_stream(stream), pattern, (unsigned)(bytes / 4), (unsigned*)nullptr);
+  return check_launch("dppm_test_fill_lds");
+}
 
 #ifdef SG_STAMP
 extern "C" int dppm_sg_read_stamps(unsigned long long* out_host) {

@@ -420,7 +420,7 @@ inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
   if (prof) prof_before(st);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(w3_mlp_kernel<NS, DEPTH>), dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
   const int rc = check_launch("w3_mlp_forward");
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
   return rc;
 }
 
@@ -561,7 +561,7 @@ inline int w3_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   else if (!trans && NS > 1) rc = w3_lin2<NS>(a, st);   // the split form of two matrices does not fit one wave's registers
   else rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 2, true>, w3_lds<NS>(), a, st, set[2], "w3_lin<2,T>")
                   : ws_launch_kernel(w3_lin_kernel<NS, 2, false>, w3_lds<NS>(), a, st, set[3], "w3_lin<2,N>");
-  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));
   return rc;
 }
 

@@ -338,6 +338,26 @@ inline int ws_check(const WsArgs& a, const char* what) {
   return DPPM_OK;
 }
 
+// Algorithmic HBM bytes of one launch for the measurement hooks: every distinct source plane set read once, every result written
+// once (read as well when accumulating), plus the saved / re-read hidden activations of the training forms.
+inline double ws_alg_bytes(const WsArgs& a, int nsrc, bool save_mid, bool reads_hidden) {
+  const float* seen[2 * WS_MAX_JOBS];
+  int ns = 0;
+  double sets = 0;
+  auto src = [&](const float* p) {
+    for (int i = 0; i < ns; ++i)
+      if (seen[i] == p) return;
+    seen[ns++] = p;
+    sets += 1;
+  };
+  for (int i = 0; i < a.njobs; ++i) {
+    src(a.job[i].X);
+    if (nsrc == 2) src(a.job[i].X2);
+    sets += 1 + (a.job[i].accumulate ? 1 : 0) + (save_mid ? 1 : 0) + (reads_hidden ? 1 : 0);
+  }
+  return sets * sizeof(float) * (double)WS_H * a.P * a.B;
+}
+
 // Linear -> LeakyReLU -> Linear (* mask) for every job; save_mid keeps the hidden activations (training).
 inline int ws_mlp_forward(const WsArgs& a, bool save_mid, hipStream_t st) {
   DPPM_TRY(ws_check(a, "ws_mlp_forward"));
@@ -350,7 +370,7 @@ inline int ws_mlp_forward(const WsArgs& a, bool save_mid, hipStream_t st) {
   if (prof) prof_before(st);
   const int rc = save_mid ? ws_launch_kernel(ws_mlp_kernel<false, false, true>, ws_mlp_lds(), a, st, set1, "ws_mlp_forward(save)")
                           : ws_launch_kernel(ws_mlp_kernel<false, false, false>, ws_mlp_lds(), a, st, set0, "ws_mlp_forward");
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, save_mid, false));
   return rc;
 }
 
@@ -365,7 +385,7 @@ inline int ws_mlp_backward(const WsArgs& a, hipStream_t st) {
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   const int rc = ws_launch_kernel(ws_mlp_kernel<true, true, true>, ws_mlp_lds(), a, st, set, "ws_mlp_backward");
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, true, true));
   return rc;
 }
 
@@ -384,7 +404,7 @@ inline int ws_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
                             : ws_launch_kernel(ws_lin_kernel<1, false>, ws_lin_lds(), a, st, set[1], "ws_lin<1,N>");
   else rc = trans ? ws_launch_kernel(ws_lin_kernel<2, true>, ws_lin_lds(), a, st, set[2], "ws_lin<2,T>")
                   : ws_launch_kernel(ws_lin_kernel<2, false>, ws_lin_lds(), a, st, set[3], "ws_lin<2,N>");
-  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs);
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));
   return rc;
 }
 

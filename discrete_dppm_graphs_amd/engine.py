@@ -129,20 +129,42 @@ def node_flags(adj):
     return adj.sum(-1).gt(1e-5).to(torch.float32)
 
 
+def empty_step(state, like, dtype, group=None, lr=None, train=True):
+    """The step of a data-parallel rank whose slice of the global batch is empty (a tail batch with fewer graphs than
+    ranks): a zero gradient contribution that still joins the all-reduce and takes the same Adam step as every other
+    rank.  Returns a zero loss on `like`'s device."""
+    if train:
+        state.grad.zero_()
+        state.all_reduce(group)
+        state.adam_step(lr)
+    return torch.zeros((), device=like.device, dtype=dtype)
+
+
+def _f64_dev(values, device):
+    """B doubles on the device: a float64 device tensor is taken as it is (the per-epoch draw table of ppgn_simple._epoch_loop:
+    no host-to-device copy per step), host values are uploaded."""
+    if isinstance(values, torch.Tensor):
+        return values.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.asarray(values, dtype=np.float64), device=device)
+
+
 def train_step_simple(model, state, adj, sigmas, seed, offset, graph_id0=0, B_global=None, group=None, lr=None):
     """One optimiser step of the simple (BCE) objective on a device-resident batch `adj` [B,N,N].
-    sigmas: B doubles (the reference draws np.random.uniform(0, .5, B), ppgn_simple.py:67).  Returns the loss as a
-    0-d float64 device tensor (this rank's share of the global mean; sum over ranks for the global value)."""
+    sigmas: B doubles, host values or a float64 device tensor (the reference draws np.random.uniform(0, .5, B),
+    ppgn_simple.py:67).  Returns the loss as a 0-d float64 device tensor (this rank's share of the global mean; sum over
+    ranks for the global value)."""
     B = adj.shape[0]
+    if B == 0:
+        return empty_step(state, adj, torch.float64, group, lr)
     flags = node_flags(adj)
-    A_t, target = ops.edgeflip(adj, flags, sigmas, seed=seed, graph_id0=graph_id0, offset=offset)
+    sig_dev = _f64_dev(sigmas, adj.device)
+    A_t, target = ops.edgeflip(adj, flags, sig_dev, seed=seed, graph_id0=graph_id0, offset=offset)
     mask = ops.generate_mask(flags)
-    sig_dev = torch.as_tensor(np.asarray(sigmas, dtype=np.float64), device=adj.device)
 
     def loss_grad(logits):
         return ops.loss_bce(logits, target, sig_dev, mask, B_global=B_global or B)
 
-    loss, _ = model.forward_backward(A_t, mask, np.asarray(sigmas, dtype=np.float64), loss_grad, state.grad_pack)
+    loss, _ = model.forward_backward(A_t, mask, sig_dev, loss_grad, state.grad_pack)
     state.all_reduce(group)
     state.adam_step(lr)
     return loss
@@ -158,18 +180,21 @@ def vlb_batch_schedule(T, t_idx):
     return np.stack([st, bt, st1], 1)
 
 
-def train_step_vlb(model, state, adj, t_idx, T, seed, offset, graph_id0=0, group=None, lr=None):
-    """One optimiser step of the VLB objective; t_idx: B integers in [1, T] (ppgn_vlb.py:161)."""
+def train_step_vlb(model, state, adj, t_idx, T, seed, offset, graph_id0=0, group=None, lr=None, sched=None):
+    """One optimiser step of the VLB objective; t_idx: B integers in [1, T] (ppgn_vlb.py:161), or `sched`: the [B,3]
+    float64 device table vlb_batch_schedule makes of them (ppgn_simple._epoch_loop uploads one per epoch)."""
+    if adj.shape[0] == 0:
+        return empty_step(state, adj, torch.float32, group, lr)
     flags = node_flags(adj)
-    sched = vlb_batch_schedule(T, t_idx)
-    A_t, _ = ops.edgeflip(adj, flags, sched[:, 0], seed=seed, graph_id0=graph_id0, offset=offset, want_target=False)
+    sched_dev = _f64_dev(vlb_batch_schedule(T, t_idx) if sched is None else sched, adj.device)
+    sig_dev = sched_dev[:, 0].contiguous()
+    A_t, _ = ops.edgeflip(adj, flags, sig_dev, seed=seed, graph_id0=graph_id0, offset=offset, want_target=False)
     mask = ops.generate_mask(flags)
-    sched_dev = torch.as_tensor(sched, device=adj.device)
 
     def loss_grad(logits):
         return ops.loss_vlb(logits, A_t, adj, sched_dev, mask)
 
-    loss, _ = model.forward_backward(A_t, mask, sched[:, 0], loss_grad, state.grad_pack)
+    loss, _ = model.forward_backward(A_t, mask, sig_dev, loss_grad, state.grad_pack)
     state.all_reduce(group)
     state.adam_step(lr)
     return loss

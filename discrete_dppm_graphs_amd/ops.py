@@ -388,10 +388,11 @@ def prof_begin(max_records=200000):
 
 
 def prof_end():
-    """-> {class: {"ms": device time, "work": FLOPs (bytes for inorm), "launches": n}}, truncated flag."""
+    """-> {class: {"ms": device time, "work": FLOPs (bytes for inorm), "bytes": algorithmic HBM bytes, "launches": n}},
+    truncated flag."""
     n = len(PROF_CLASSES)
-    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_long * n)()
-    rc = lib.dppm_prof_end(ms, work, cnt, n)
+    ms, work, nbytes, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_long * n)()
+    rc = lib.dppm_prof_end(ms, work, nbytes, cnt, n)
     if rc < 0:
         check(rc, "dppm_prof_end")
-    return {k: {"ms": ms[i], "work": work[i], "launches": cnt[i]} for i, k in enumerate(PROF_CLASSES)}, rc == 1
+    return {k: {"ms": ms[i], "work": work[i], "bytes": nbytes[i], "launches": cnt[i]} for i, k in enumerate(PROF_CLASSES)}, rc == 1

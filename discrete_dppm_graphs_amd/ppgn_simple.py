@@ -16,6 +16,7 @@ from .sample_ppgn_simple import sample_main, sample_testing
 from .utils.arg_helper import edict2dict, get_config, load_data, parse_arguments, process_config, set_seed_and_logger
 from .utils.easydict import EasyDict as edict
 from .utils.loading_utils import get_score_model
+from .utils.resident import STREAM_NOISE, batch_sizes_of, host_rng, upload
 
 _SAMPLERS = (sample_main, sample_testing)
 
@@ -69,26 +70,48 @@ def _resume(resume, model, state, config, lr0, gamma):
     lr0 = float(sched.get('base_lr', lr0))
     gamma = float(sched.get('gamma', gamma))
     first_epoch = int(ckp['epoch']) + 1
-    state.lr = lr0 * gamma ** first_epoch
+    state.lr = lr_after_epoch(lr0, gamma, first_epoch - 1)
     logging.info(f"resumed from epoch {ckp['epoch']} (step {state.step_count}, lr {state.lr:.3e})")
     return lr0, gamma, first_epoch
 
 
+def lr_after_epoch(lr0, gamma, epoch):
+    """Learning rate in force once epoch `epoch` has finished (epoch = -1: before the first one).  The reference builds
+    ExponentialLR and calls scheduler.step(epoch) after every epoch (ppgn_simple.py:56,95), which sets the closed form
+    lr0 * gamma**epoch: epochs 0 and 1 both run at lr0, epoch 2 at lr0 * gamma, ..."""
+    return lr0 * gamma ** max(epoch, 0)
+
+
 def _epoch_loop(model, state, dl, config, step_fn, train, epoch, counters):
-    """One pass over a loader; each rank processes its slice of every batch."""
+    """One pass over a loader; each rank processes its slice of every global batch.
+    The host randomness of the whole pass (one noise draw per graph) is made up front by counters["plan"] from a generator
+    keyed by (seed, epoch, train / test) -- identical on every rank, whatever the world size -- and uploaded once; with a
+    ResidentLoader no step copies anything from the host (config.assert_no_host_sync = True turns every synchronising
+    host<->device transfer after the first step of a pass into an error: tests/test_gpu_resident.py).
+    A rank whose slice of a (tail) batch is empty still takes the step with a zero gradient, so the all-reduce of the
+    other ranks is always matched."""
     dist, rank, world = _dist()
-    losses = []
-    for adj_b, _x_b in dl:
-        Bg = adj_b.size(0)
-        sigmas = counters["draw"](Bg)                       # host draw for the GLOBAL batch (same on every rank)
-        lo, hi = shard_bounds(Bg, rank, world)
-        if hi <= lo:
-            continue
-        adj = adj_b[lo:hi].to(config.dev).contiguous()
-        loss = step_fn(model, state, adj, sigmas[lo:hi], Bg, counters["gid"] + lo, counters["offset"], train)
-        counters["offset"] += 1
-        counters["gid"] += Bg
-        losses.append(loss)
+    sizes = batch_sizes_of(dl)
+    pass_no = 2 * epoch + (0 if train else 1)
+    plan = counters["plan"](int(sum(sizes)), pass_no, config.dev)     # device tensor, leading dimension = graphs of the pass
+    guard = bool(getattr(config, "assert_no_host_sync", False)) and torch.cuda.is_available()
+    old_mode = torch.cuda.get_sync_debug_mode() if guard else 0
+    losses, first = [], 0
+    try:
+        for step, (adj_b, _x_b) in enumerate(dl):
+            Bg = adj_b.size(0)
+            lo, hi = shard_bounds(Bg, rank, world)
+            adj = adj_b[lo:hi].to(config.dev).contiguous()
+            # Philox counters: graph id = position of the graph in this pass, call offset = (pass, step); a resumed run
+            # continues the streams of the run it resumes
+            loss = step_fn(model, state, adj, plan[first + lo:first + hi], Bg, first + lo, (pass_no << 12) + (step & 0xFFF), train)
+            first += Bg
+            losses.append(loss)
+            if guard:
+                torch.cuda.set_sync_debug_mode("error")
+    finally:
+        if guard:
+            torch.cuda.set_sync_debug_mode(old_mode)
     if not losses:
         return float('nan')
     tot = torch.stack([l.double() for l in losses])
@@ -114,15 +137,24 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
     first_epoch = 0
     if resume is not None:
         lr0, gamma, first_epoch = _resume(resume, model, state, config, lr0, gamma)
+    if hasattr(train_dl, "epoch"):
+        train_dl.epoch = first_epoch                         # shuffle order of a ResidentLoader is keyed by the epoch
     best_score, best_score_loss = np.inf, np.inf
     lastmmd = {n: {"degree": 0, "cluster": 0, "orbit": 0.0} for n in config.num_levels}
-    host_rng = np.random      # the reference draws sigmas from numpy's global generator (ppgn_simple.py:67)
-    counters = {"offset": 0, "gid": 0, "draw": lambda B: host_rng.uniform(low=0.0, high=0.5, size=B)}
     seed = int(getattr(config, "seed", 0))
+
+    def plan(n, pass_no, dev):
+        # sigma_b ~ U(0, 1/2), one per graph (ppgn_simple.py:67 draws them from numpy's unseeded global generator); here they
+        # come from a generator keyed by (seed, pass), so every rank holds the same draws for the same global graph
+        return upload(host_rng(seed, STREAM_NOISE, pass_no).uniform(low=0.0, high=0.5, size=n), dev, torch.float64)
+
+    counters = {"plan": plan}
 
     def step_fn(model, state, adj, sigmas, Bg, gid0, offset, train):
         if train:
             return engine.train_step_simple(model, state, adj, sigmas, seed, offset, gid0, B_global=Bg, lr=state.lr)
+        if adj.shape[0] == 0:
+            return engine.empty_step(state, adj, torch.float64, train=False)
         flags = engine.node_flags(adj)
         A_t, target = ops.edgeflip(adj, flags, sigmas, seed=seed + 1, graph_id0=gid0, offset=offset)
         mask = ops.generate_mask(flags)
@@ -134,12 +166,12 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
         t_start = time.time()
         model.train()
         mean_train_loss = _epoch_loop(model, state, train_dl, config, step_fn, True, epoch, counters)
-        state.lr = lr0 * gamma ** (epoch + 1)                # ExponentialLR stepped once per epoch (:56,95)
+        state.lr = lr_after_epoch(lr0, gamma, epoch)         # scheduler.step(epoch) (:56,95)
         model.eval()
         mean_test_loss = _epoch_loop(model, state, test_dl, config, step_fn, False, epoch, counters) if test_dl is not None else float('nan')
         logging.info(f'epoch: {epoch:03d}| time: {time.time() - t_start:.1f}s| train loss: {mean_train_loss:+.3e} | '
                      f'test loss: {mean_test_loss:+.3e} | ')
-        sched_state = {'gamma': gamma, 'last_epoch': epoch + 1, 'base_lr': lr0}
+        sched_state = {'gamma': gamma, 'last_epoch': epoch, 'base_lr': lr0}
         if rank == 0:
             if epoch % save_interval == save_interval - 1:
                 _save(config, model, state, sched_state, sigma_list, epoch, mean_train_loss, mean_test_loss)
@@ -182,17 +214,23 @@ def train_main(config, args):
                resume=getattr(args, "resume", None) or None)
 
 
-def main(argv=None):
-    args = parse_arguments('train_ego_small.yaml', argv)
-    ori_config_dict = get_config(args)
-    config_dict = edict(ori_config_dict.copy())
-    config_dict.model.name = "ppgn"          # reference ppgn_simple.py:285
+def init_distributed():
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE): pick the rank's device and join
+    the RCCL process group BEFORE the configuration is processed, so that rank 0 names the run directory for everyone."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", 0))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        config_dict.dev = torch.device("cuda", local)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+
+def main(argv=None):
+    args = parse_arguments('train_ego_small.yaml', argv)
+    init_distributed()
+    ori_config_dict = get_config(args)
+    config_dict = edict(ori_config_dict.copy())
+    config_dict.model.name = "ppgn"          # reference ppgn_simple.py:285
     train_main(config_dict, args)
 
 

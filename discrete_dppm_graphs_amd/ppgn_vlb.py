@@ -15,6 +15,7 @@ from .sample_ppgn_vlb import sample_main, sample_testing
 from .utils.arg_helper import get_config, load_data, parse_arguments, set_seed_and_logger
 from .utils.easydict import EasyDict as edict
 from .utils.loading_utils import get_score_model
+from .utils.resident import STREAM_NOISE, host_rng, upload
 
 
 class _VlbLoss(torch.autograd.Function):
@@ -43,25 +44,29 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
     """reference ppgn_vlb.py:127-331; epoch bookkeeping shared with ppgn_simple.fit, step = engine.train_step_vlb."""
     T = config.num_levels[0]
     seed = int(getattr(config, "seed", 0))
-    host_rng = np.random
 
-    def draw(B):    # np.random.random_integers(1, T, B) in the reference (:161); randint's upper bound is exclusive
-        return host_rng.randint(1, T + 1, size=B)
+    def plan(n, pass_no, dev):
+        # t_b ~ UniformInt[1, T], one per graph (np.random.random_integers(1, T, B) in the reference, :161), from a generator
+        # keyed by (seed, pass) and identical on every rank; uploaded as the [n, 3] table (sigmatilde_t, beta_t, sigmatilde_{t-1})
+        t_idx = host_rng(seed, STREAM_NOISE, pass_no).integers(1, T + 1, size=n)
+        return upload(engine.vlb_batch_schedule(T, t_idx), dev, torch.float64)
 
-    def step_fn(model, state, adj, t_idx, Bg, gid0, offset, train):
+    def step_fn(model, state, adj, sched, Bg, gid0, offset, train):
         if train:
-            return engine.train_step_vlb(model, state, adj, t_idx, T, seed, offset, gid0, lr=state.lr)
+            return engine.train_step_vlb(model, state, adj, None, T, seed, offset, gid0, lr=state.lr, sched=sched)
+        if adj.shape[0] == 0:
+            return engine.empty_step(state, adj, torch.float32, train=False)
         flags = engine.node_flags(adj)
-        sched = engine.vlb_batch_schedule(T, t_idx)
-        A_t, _ = ops.edgeflip(adj, flags, sched[:, 0], seed=seed + 1, graph_id0=gid0, offset=offset, want_target=False)
+        sig = sched[:, 0].contiguous()
+        A_t, _ = ops.edgeflip(adj, flags, sig, seed=seed + 1, graph_id0=gid0, offset=offset, want_target=False)
         mask = ops.generate_mask(flags)
-        loss, _ = ops.loss_vlb(model.infer(A_t, mask, sched[:, 0]), A_t, adj, sched, mask, want_grad=False)
+        loss, _ = ops.loss_vlb(model.infer(A_t, mask, sig), A_t, adj, sched, mask, want_grad=False)
         return loss
 
-    return _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, draw, step_fn, resume)
+    return _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, plan, step_fn, resume)
 
 
-def _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, draw, step_fn, resume=None):
+def _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, sample_interval, test_dl, plan, step_fn, resume=None):
     import time
     dist, rank, world = _simple._dist()
     if isinstance(optimizer, engine.FlatState):
@@ -73,17 +78,19 @@ def _fit_generic(model, optimizer, train_dl, max_epoch, config, save_interval, s
     first_epoch = 0
     if resume is not None:
         lr0, gamma, first_epoch = _simple._resume(resume, model, state, config, lr0, gamma)
+    if hasattr(train_dl, "epoch"):
+        train_dl.epoch = first_epoch
     best_score, best_score_loss = np.inf, np.inf
-    counters = {"offset": 0, "gid": 0, "draw": draw}
+    counters = {"plan": plan}
     for epoch in range(first_epoch, max_epoch):
         t0 = time.time()
         model.train()
         tr = _simple._epoch_loop(model, state, train_dl, config, step_fn, True, epoch, counters)
-        state.lr = lr0 * gamma ** (epoch + 1)
+        state.lr = _simple.lr_after_epoch(lr0, gamma, epoch)
         model.eval()
         te = _simple._epoch_loop(model, state, test_dl, config, step_fn, False, epoch, counters) if test_dl is not None else float('nan')
         logging.info(f'epoch: {epoch:03d}| time: {time.time() - t0:.1f}s| train loss: {tr:+.3e} | test loss: {te:+.3e} | ')
-        sched_state = {'gamma': gamma, 'last_epoch': epoch + 1, 'base_lr': lr0}
+        sched_state = {'gamma': gamma, 'last_epoch': epoch, 'base_lr': lr0}
         if rank == 0:
             if epoch % save_interval == save_interval - 1:
                 _simple._save(config, model, state, sched_state, [0.0], epoch, tr, te)
@@ -122,14 +129,9 @@ def train_main(config, args):
 
 def main(argv=None):
     args = parse_arguments('train_ego_small.yaml', argv)
+    _simple.init_distributed()
     config_dict = edict(get_config(args).copy())
     config_dict.model.name = "ppgn"
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", 0))
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        config_dict.dev = torch.device("cuda", local)
     train_main(config_dict, args)
 
 

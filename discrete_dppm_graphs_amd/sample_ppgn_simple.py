@@ -14,6 +14,7 @@ from . import engine
 from .evaluation.stats import adjs_to_graphs, eval_graph_list
 from .utils.arg_helper import graphs_to_tensor, load_data, load_model
 from .utils.loading_utils import prepare_test_model_train
+from .utils.resident import STREAM_POOL, host_rng, upload
 
 _CALLS = {"n": 0}
 
@@ -53,31 +54,37 @@ def gather_batches(mine, n_batches, B, rank, world, dist):
 
 def run_sample(config, model, pool_adjs, eval_len, noise_num, chain, ref_graphs, methods=None):
     """reference sample_ppgn_simple.py:70-99 (run_sample).  pool_adjs: [G, N, N] padded training adjacencies from which
-    node counts are drawn (gen_init_data, :24-41)."""
+    node counts are drawn (gen_init_data, :24-41): moved to the device once (a ResidentLoader's pool already lives there),
+    reduced to node flags [G, N] once, and indexed there.  The pool indices of ALL batches of the call come from one host
+    generator keyed by (seed, call number) -- every rank draws the same table and keeps its own batches -- and cross to the
+    device in one copy before the first chain starts."""
     dist, rank, world = _dist()
     B = config.test.batch_size
     dev = torch.device(config.dev)
-    seed = int(getattr(config, "seed", 0)) + 7919 * _CALLS["n"]
+    call = _CALLS["n"]
     _CALLS["n"] += 1
+    seed = int(getattr(config, "seed", 0)) + 7919 * call
     n_batches = -(-eval_len // B)
-    idx = [np.random.randint(0, len(pool_adjs), B) for _ in range(n_batches)]   # every rank draws all, keeps its own
+    idx = host_rng(int(getattr(config, "seed", 0)), STREAM_POOL, call).integers(0, len(pool_adjs), size=(n_batches, B))
     m = engine.chain_width(model, pool_adjs.shape[-1], B, -(-n_batches // world))
+    n_graphs = n_batches * B
     if m > 1:       # small graphs: m consecutive batches per chain call (same graph ids, same samples)
-        idx = [np.concatenate(idx[k:k + m]) for k in range(0, n_batches, m)]
-        if len(idx[-1]) < m * B:                                                 # ragged tail: pad with repeats, cut after the gather
-            idx[-1] = np.concatenate([idx[-1], np.resize(idx[-1], m * B - len(idx[-1]))])
-        n_graphs, n_batches, B = n_batches * B, len(idx), m * B
+        flat = idx.reshape(-1)
+        n_wide = -(-n_batches // m)
+        if n_wide * m * B > flat.size:                                           # ragged tail: pad with repeats, cut after the gather
+            flat = np.concatenate([flat, np.resize(flat[-((n_batches - 1) % m + 1) * B:], n_wide * m * B - flat.size)])
+        idx, n_batches, B = flat.reshape(n_wide, m * B), n_wide, m * B
+    pool_flags = _flags_from_adjs(pool_adjs.to(dev)).contiguous()               # [G, N], resident
+    idx_dev = upload(idx, dev, torch.int64)
     mine = []
     with torch.no_grad():
         for bi in my_batches(n_batches, rank, world):
-            flags = _flags_from_adjs(pool_adjs[idx[bi]].to(dev))
-            adjs = chain(model, flags.contiguous(), noise_num, seed, graph_id0=bi * B)
+            flags = pool_flags.index_select(0, idx_dev[bi])
+            adjs = chain(model, flags, noise_num, seed, graph_id0=bi * B)
             mine.append(adjs.to(torch.uint8))
     N = pool_adjs.shape[-1]
     mine = torch.cat(mine) if mine else torch.zeros(0, N, N, dtype=torch.uint8, device=dev)
-    allg = gather_batches(mine, n_batches, B, rank, world, dist)
-    if m > 1:
-        allg = allg[:n_graphs]
+    allg = gather_batches(mine, n_batches, B, rank, world, dist)[:n_graphs]
     gen_graph_list = adjs_to_graphs(allg.cpu().numpy().astype(np.float32))
     result_dict = eval_graph_list(ref_graphs, gen_graph_list, methods=methods)
     return result_dict, gen_graph_list
@@ -105,8 +112,8 @@ def sample_main(config, modellink, epoch, noise_num, chain=None):
 def sample_testing(config, modellink, epoch, noise_num, train_dl, chain=None):
     """reference sample_ppgn_simple.py:106-187: as sample_main but node counts and the MMD reference come from the
     training loader, and 256 graphs are drawn (:186)."""
-    pool = torch.cat([adj for adj, _ in train_dl]).cpu()
+    pool = train_dl.pool() if hasattr(train_dl, "pool") else torch.cat([adj for adj, _ in train_dl])
     model = _load(config, modellink)
-    train_graphs = adjs_to_graphs(pool.numpy())
+    train_graphs = adjs_to_graphs(pool.cpu().numpy())
     result_dict, _ = run_sample(config, model, pool, 256, noise_num, chain or engine.sample_chain_simple, train_graphs)
     return result_dict

@@ -6,15 +6,13 @@ from .engine import sigma_lin  # noqa: F401  (reference sample_ppgn_vlb.py:28-35
 
 
 def posterior(sigmatilde_t, sigma_t, sigmatilde_t1, x0, xt):
-    """reference sample_ppgn_vlb.py:17-25 (scalar form, unused by the sampler itself)."""
-    if xt < 0.01 and x0 < 0.01:
-        return sigmatilde_t1 * sigma_t / (1 - sigmatilde_t)
-    elif xt > 0.99 and x0 < 0.01:
-        return sigmatilde_t1 * (1 - sigma_t) / (sigmatilde_t)
-    elif xt > 0.99 and x0 > 0.99:
-        return (1 - sigmatilde_t1) * (1 - sigma_t) / (1 - sigmatilde_t)
-    if xt < 0.01 and x0 > 0.99:
-        return (1 - sigmatilde_t1) * sigma_t / (sigmatilde_t)
+    """q(x_{t-1} = 1 | x_t, x_0) for one binary edge, by Bayes' rule: prior q(x_{t-1}=1 | x_0) times likelihood
+    q(x_t | x_{t-1}=1) over evidence q(x_t | x_0).  Same name and argument order as the scalar helper at reference
+    sample_ppgn_vlb.py:17-25 (which the reference's sampler never calls either); the kernels evaluate the tensor form."""
+    prior = 1 - sigmatilde_t1 if x0 > 0.5 else sigmatilde_t1
+    likelihood = 1 - sigma_t if xt > 0.5 else sigma_t
+    evidence = 1 - sigmatilde_t if (xt > 0.5) == (x0 > 0.5) else sigmatilde_t
+    return prior * likelihood / evidence
 
 
 def sample_main(config, modellink, epoch, noise_num):

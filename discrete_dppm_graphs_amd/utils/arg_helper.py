@@ -10,11 +10,18 @@ import time
 import numpy as np
 import torch
 import yaml
-from torch.utils.data import DataLoader, TensorDataset
 
 from .easydict import EasyDict as edict
 from .graph_utils import pad_adjs, set_rng
 from .loading_utils import get_score_model
+from .resident import ResidentLoader
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
 
 
 def parse_arguments(default_config="train.yaml", argv=None):
@@ -38,22 +45,32 @@ def get_config(args):
 
 
 def process_config(config, comment=''):
-    """reference :50-76."""
-    dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    config.dev = dev
-    config.run_id = str(os.getpid())
-    config.folder_name = '_'.join([config.model.name, config.dataset.name, comment.replace(' ', '_'),
-                                   time.strftime('%b-%d-%H-%M-%S'), config.run_id])
+    """reference :50-76.  Under torch.distributed (one process per GPU) the run directory is named by rank 0 and handed to
+    the other ranks, so that every rank reads the checkpoints rank 0 writes; only rank 0 creates directories and the
+    config snapshot."""
+    dist, rank, world = _dist()
+    if not torch.cuda.is_available():
+        config.dev = torch.device("cpu")
+    else:       # one process per GPU: the rank's own device (set by the launcher code before the process group exists)
+        config.dev = torch.device("cuda", torch.cuda.current_device()) if world > 1 else torch.device("cuda")
+    names = [str(os.getpid()), time.strftime('%b-%d-%H-%M-%S')]
+    if world > 1:
+        dist.broadcast_object_list(names, src=0)
+    config.run_id = names[0]
+    config.folder_name = '_'.join([config.model.name, config.dataset.name, comment.replace(' ', '_'), names[1], config.run_id])
     if 'save_dir' not in config:
         config.save_dir = os.path.join(config.exp_dir, config.exp_name, config.folder_name)
     if 'model_save_dir' not in config:
         config.model_save_dir = os.path.join(config.save_dir, 'models')
-    mkdir(config.exp_dir)
-    mkdir(config.save_dir)
-    mkdir(config.model_save_dir)
-    save_name = os.path.join(config.save_dir, 'config.yaml')
-    with open(save_name, 'w') as f:
-        yaml.dump(edict2dict(config), f, default_flow_style=False)
+    if rank == 0:
+        mkdir(config.exp_dir)
+        mkdir(config.save_dir)
+        mkdir(config.model_save_dir)
+        save_name = os.path.join(config.save_dir, 'config.yaml')
+        with open(save_name, 'w') as f:
+            yaml.dump(edict2dict(config), f, default_flow_style=False)
+    if world > 1:
+        dist.barrier()
 
 
 def edict2dict(edict_obj):
@@ -75,18 +92,21 @@ def mkdir(folder):
 
 
 def set_seed(config, args=None):
-    """reference :116-127 (plus the Philox stream of the HIP kernels)."""
+    """reference :116-127 (plus the Philox stream of the HIP kernels).  The reference's `np.random.RandomState(seed)`
+    (:101) builds and drops a generator, leaving numpy's global state unseeded; nothing on this package's path draws from
+    that global state (utils/resident.host_rng), it is seeded here only for user code."""
     random.seed(config.seed)
     torch.manual_seed(config.seed)
     torch.cuda.manual_seed_all(config.seed)
-    np.random.RandomState(config.seed)
+    np.random.seed(int(config.seed) & 0xFFFFFFFF)
     set_rng(config.seed)
 
 
 def set_seed_and_logger(config, args):
     """reference :97-114."""
     set_seed(config)
-    log_file = os.path.join(config.save_dir, args.log_level.lower() + ".log")
+    _, rank, _ = _dist()
+    log_file = os.path.join(config.save_dir, args.log_level.lower() + (".log" if rank == 0 else f".rank{rank}.log"))
     FORMAT = args.comment + '| %(asctime)s %(message)s'
     fh = logging.FileHandler(log_file)
     fh.setLevel(args.log_level)
@@ -136,10 +156,11 @@ def graphs_to_tensor(config, graph_list):
 
 
 def graphs_to_dataloader(config, graph_list):
-    """reference :130-134."""
+    """reference :130-134 (DataLoader(TensorDataset(adjs, x), batch_size, shuffle=True)), with the padded tensors uploaded
+    once and batches indexed on the device (utils/resident.py)."""
     adjs_tensor, x_tensor = graphs_to_tensor(config, graph_list)
-    train_ds = TensorDataset(adjs_tensor, x_tensor)
-    return DataLoader(train_ds, batch_size=config.train.batch_size, shuffle=True)
+    return ResidentLoader(adjs_tensor, x_tensor, batch_size=config.train.batch_size, shuffle=True,
+                          seed=int(getattr(config, "seed", 0)), device=config.dev)
 
 
 def load_dataset(data_dir='data', file_name=None):

@@ -31,6 +31,21 @@ def generate_mask(flags):
     return f.unsqueeze(-1) * f.unsqueeze(-2)
 
 
+def generate_mask_loop(flags):
+    """The same mask built the way the reference builds it (utils/graph_utils.py:312-319): one Python-level visit per
+    (graph, i, j) with tensor-scalar comparisons, on the CPU.  Only bench.py's reference-faithful CPU baseline times this;
+    tests check it equals generate_mask."""
+    flags = _t(flags)
+    B, N = flags.shape
+    out = torch.zeros(B, N, N)
+    for b, row in enumerate(flags):
+        for i, fi in enumerate(row):
+            for j, fj in enumerate(row):
+                if fj >= 0.9 and fi >= 0.9:
+                    out[b][i][j] = 1
+    return out
+
+
 def mask_adjs(adjs, flags):
     """reference utils/graph_utils.py:7-19 (3-D case)."""
     adjs, flags = _t(adjs), _t(flags)
@@ -61,6 +76,20 @@ def gen_init_data(flags, U):
     bern = 0.5 * act.unsqueeze(-1) * act.unsqueeze(-2)
     upper = (U < bern).to(F32).triu(diagonal=1)
     return upper + upper.transpose(-1, -2)
+
+
+def gen_init_prob_loop(flags):
+    """The p = 1/2 matrix of gen_init_data built as the reference builds it (sample_ppgn_simple.py:32-37): a Python loop over
+    every (graph, i, j) with tensor-scalar reads.  Timed by bench.py's reference-faithful CPU baseline only."""
+    flags = _t(flags)
+    B, N = flags.shape
+    bern = torch.zeros(B, N, N)
+    for k in range(B):
+        for i in range(N):
+            for j in range(N):
+                if 1 / 2 < flags[k][i] and 1 / 2 < flags[k][j]:
+                    bern[k, i, j] = 1 / 2
+    return bern
 
 
 def probs_from_logits(logits):

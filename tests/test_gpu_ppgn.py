@@ -465,3 +465,28 @@ np.savez(sys.argv[1], **g)
         assert err <= tol * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
         differs |= err > 0
     assert differs       # the switch did select the other kernel
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("bf16x3", 1e-3)])
+def test_headline_geometry_vs_float32_oracle(ops, precision, tol):
+    """BASELINE configs[3] geometry (N = 200, 8 x 128) against the float32 oracle directly: two graphs, one full and one ragged
+    (137 active nodes), per-graph sigma; exact-f32 kernels to 2e-4 and the bf16x3 mode bench.py times to the 1e-3 bar."""
+    from oracle import ppgn as op
+    B, N, H, L = 2, 200, 128, 8
+    rng = np.random.default_rng(2024)
+    A = np.zeros((B, N, N), np.float32)
+    for b, n in enumerate((200, 137)):
+        blocks = rng.integers(0, 8, size=n)
+        up = np.triu(rng.random((n, n)) < np.where(blocks[:, None] == blocks[None, :], 0.3, 0.005), 1).astype(np.float32)
+        for i in range(n - 1):
+            up[i, i + 1] = 1
+        A[b, :n, :n] = up + up.T
+    flags = (A.sum(-1) > 1e-5).astype(np.float32)
+    mask = flags[:, :, None] * flags[:, None, :]
+    sigma = np.array([0.31, 0.07])
+    W = op.init_weights(L, H, seed=1234)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    close(got * mask, ref * mask, tol=tol)
+    close(got, ref, tol=tol)

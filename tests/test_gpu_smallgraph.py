@@ -101,3 +101,23 @@ def test_run_sample_carries_several_batches_per_chain_call(monkeypatch):
     assert got["merged"][0].shape[0] == 24 - 2 or got["merged"][0].shape[0] == 24      # 22 asked: 6 batches of 4 drawn, as the reference does
     assert np.array_equal(got["merged"][0][:22], got["single"][0][:22])
     assert got["merged"][0][:22].sum() > 0
+
+
+@pytest.mark.parametrize("N", [13, 17, 18, 19])
+def test_fused_forward_ignores_stale_lds(ops, N):
+    """N % 4 != 0: rows N .. ld-1 of the o2 planes are LDS words the kernel never writes.  With every CU's LDS poisoned with a quiet
+    NaN (then +Inf) bit pattern beforehand, the logits must still equal the general path's: no uninitialised word may reach a
+    product (0 * NaN would)."""
+    import ctypes as C
+    from discrete_dppm_graphs_amd._lib import check, lib
+    from oracle import ppgn as op
+    rng = np.random.default_rng(300 + N)
+    A, mask = rand_case(rng, 40, N, ragged=True)
+    sigma = rng.uniform(0, 0.5, size=40)
+    W = op.init_weights(3, 32, seed=N)
+    want = _general(ops, W, A, mask, sigma, 3, 32)
+    for pattern in (0x7FC00000, 0x7F800000):
+        check(lib.dppm_test_fill_lds(pattern, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dppm_test_fill_lds")
+        got, _ = run_gpu(ops, W, A, mask, sigma, 3, 32)
+        assert np.isfinite(got).all()
+        close(got, want, tol=5e-5)
