@@ -210,11 +210,21 @@ def chain_width(model, N, B, n_batches, cus=256):
     return max(1, min(n_batches, cus // max(B, 1))) if small else 1
 
 
+_SIGMA_ROWS = {}
+
+
 def _sigma_rows(levels, like):
-    """[T, B] float32 on the device, row c = the noise level of chain step c for every graph: one host-to-device copy per chain
-    instead of one (stream-synchronising) copy per level; the values are the float32 roundings model._prepare would make."""
-    col = torch.as_tensor(np.asarray(levels, dtype=np.float64).astype(np.float32), device=like.device)
-    return col.view(-1, 1).expand(-1, like.shape[0]).contiguous()
+    """[T, B] float32 on the device, row c = the noise level of chain step c for every graph; the values are the float32
+    roundings model._prepare would make.  A schedule is a pure function of the number of levels, so the table is uploaded once
+    per (schedule, batch size, device) and kept: the chains of a sampling call copy nothing from the host."""
+    key = (tuple(levels), like.shape[0], str(like.device))
+    rows = _SIGMA_ROWS.get(key)
+    if rows is None:
+        if len(_SIGMA_ROWS) > 64:
+            _SIGMA_ROWS.clear()
+        col = torch.as_tensor(np.asarray(levels, dtype=np.float64).astype(np.float32), device=like.device)
+        rows = _SIGMA_ROWS[key] = col.view(-1, 1).expand(-1, like.shape[0]).contiguous()
+    return rows
 
 
 @torch.no_grad()

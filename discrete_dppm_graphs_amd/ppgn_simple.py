@@ -158,7 +158,7 @@ def fit(model, optimizer, mcmc_sampler, train_dl, max_node_number, max_epoch=20,
         flags = engine.node_flags(adj)
         A_t, target = ops.edgeflip(adj, flags, sigmas, seed=seed + 1, graph_id0=gid0, offset=offset)
         mask = ops.generate_mask(flags)
-        loss, _ = ops.loss_bce(model.infer(A_t, mask, np.asarray(sigmas)), target, sigmas, mask, B_global=Bg, want_grad=False)
+        loss, _ = ops.loss_bce(model.infer(A_t, mask, sigmas), target, sigmas, mask, B_global=Bg, want_grad=False)
         return loss
 
     sigma_list = [0.0]
