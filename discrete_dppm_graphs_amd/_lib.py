@@ -50,6 +50,7 @@ SIGNATURES = {
     "dppm_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dppm_loss_bce_fwd_bwd": (C.c_int, [c_f32p, c_f32p, c_f64p, c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f32p,
                                         C.c_void_p, C.c_size_t, c_stream]),
+    "dppm_loss_bce_fwd_bwd_noalloc": (C.c_int, [c_f32p, c_f32p, c_f64p, c_f32p, C.c_int, C.c_int, C.c_int, c_f64p, c_f32p, c_stream]),
     "dppm_loss_vlb_fwd_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f64p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p,
                                         C.c_void_p, C.c_size_t, c_stream]),
     "dppm_ppgn_workspace_bytes": (C.c_size_t, [C.c_int] * 5),

@@ -7,6 +7,7 @@
 // This translation unit is compiled with -ffp-contract=off: the reverse-step arithmetic must reproduce the
 // reference's float32 operation order bit for bit (no FMA contraction).  File:line citations are to the
 // reference tree (kilianhae/discrete_DPPM_Graphs).
+#include <mutex>
 #include "dppm_common.h"
 #include "dppm_philox.h"
 
@@ -318,6 +319,37 @@ constexpr int kLossBlocksPerGraph = 8;
 }  // namespace
 }  // namespace dppm
 
+// Scratch of dppm_loss_bce_fwd_bwd_noalloc (include/dppm_hip.h): the per-block partial sums the workspace argument carries in
+// dppm_loss_bce_fwd_bwd, for up to DPPM_NOALLOC_MAX_GRAPHS graphs per call (256 KiB).  Each GPU the library runs on holds its own
+// copy of this array at its own address until the process ends.  Host code never uses the NAME below as an address (that is a
+// host-side stand-in): the device address is looked up once per device with hipGetSymbolAddress and kept in noalloc_scratch_ptr.
+static __device__ __align__(256) double loss_noalloc_scratch[DPPM_NOALLOC_MAX_GRAPHS * 8];
+
+namespace dppm {
+namespace {
+constexpr int kMaxDevices = 64;
+double* g_noalloc_ptr[kMaxDevices];      // per device: address of that device's copy of loss_noalloc_scratch (null = not looked up yet)
+std::mutex g_noalloc_mutex;
+
+// address of the current device's scratch array, looked up on the first call on that device (with that device current)
+int noalloc_scratch_ptr(double** out) {
+  int devid = -1;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= kMaxDevices)
+    return fail(DPPM_E_LAUNCH, "dppm_loss_bce_fwd_bwd_noalloc: cannot identify the current device (%d)", devid);
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (!g_noalloc_ptr[devid]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(loss_noalloc_scratch));
+    if (e != hipSuccess || !p)
+      return fail(DPPM_E_LAUNCH, "dppm_loss_bce_fwd_bwd_noalloc: hipGetSymbolAddress failed on device %d: %s", devid, hipGetErrorString(e));
+    g_noalloc_ptr[devid] = static_cast<double*>(p);
+  }
+  *out = g_noalloc_ptr[devid];
+  return DPPM_OK;
+}
+}  // namespace
+}  // namespace dppm
+
 using namespace dppm;
 
 extern "C" int dppm_generate_mask(const float* flags, int B, int N, float* mask, void* stream) {
@@ -387,6 +419,24 @@ extern "C" int dppm_loss_bce_fwd_bwd(const float* score, const float* target, co
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fold_partials_kernel<double>), dim3(1), dim3(256), 0, as_stream(stream), partials,
                      B * kLossBlocksPerGraph, loss_out);
   return check_launch("dppm_loss_bce_fwd_bwd(fold)");
+}
+
+extern "C" int dppm_loss_bce_fwd_bwd_noalloc(const float* score, const float* target, const double* sigma_dev, const float* mask,
+                                             int B, int N, int B_global, double* loss_out, float* dscore, void* stream) {
+  DPPM_REQUIRE(score && target && sigma_dev && mask && loss_out, "dppm_loss_bce_fwd_bwd_noalloc: null pointer");
+  DPPM_REQUIRE(B > 0 && N > 0 && B_global >= B, "dppm_loss_bce_fwd_bwd_noalloc: B=%d N=%d B_global=%d", B, N, B_global);
+  DPPM_REQUIRE(B <= DPPM_NOALLOC_MAX_GRAPHS, "dppm_loss_bce_fwd_bwd_noalloc: B=%d exceeds the built-in scratch (at most %d graphs per call); "
+               "use dppm_loss_bce_fwd_bwd with a workspace", B, DPPM_NOALLOC_MAX_GRAPHS);
+  static_assert(kLossBlocksPerGraph == 8, "loss_noalloc_scratch is sized for 8 partial sums per graph");
+  double* partials = nullptr;
+  DPPM_TRY(noalloc_scratch_ptr(&partials));
+  // every one of the B * 8 slots the fold reads is written by the first kernel of this call: nothing has to start at zero
+  hipLaunchKernelGGL(loss_bce_kernel, dim3(kLossBlocksPerGraph, B), dim3(256), 0, as_stream(stream), score, target,
+                     sigma_dev, mask, N, B_global, dscore, partials);
+  DPPM_TRY(check_launch("dppm_loss_bce_fwd_bwd_noalloc"));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fold_partials_kernel<double>), dim3(1), dim3(256), 0, as_stream(stream), (const double*)partials,
+                     B * kLossBlocksPerGraph, loss_out);
+  return check_launch("dppm_loss_bce_fwd_bwd_noalloc(fold)");
 }
 
 extern "C" int dppm_loss_vlb_fwd_bwd(const float* score, const float* A_t, const float* A_0, const double* sched_dev,

@@ -107,6 +107,16 @@ int dppm_loss_bce_fwd_bwd(const float* score, const float* target, const double*
                           int B, int N, int B_global, double* loss_out, float* dscore,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same loss for callers that cannot allocate or pass a workspace (code under HIP graph capture, tight serving / training loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The partial sums live in a file-scope device array of the
+ * library (256 KiB per GPU, held until the process ends) instead of a caller workspace; the call makes no hipMalloc / hipFree /
+ * allocating library call.  At most DPPM_NOALLOC_MAX_GRAPHS graphs per call (more: DPPM_E_INVALID, use the entry point above).
+ * All calls on one GPU share that array: calls that overlap on one GPU (different streams, or threads) race; calls on one stream
+ * are ordered and safe.  Results are bit-identical to dppm_loss_bce_fwd_bwd. */
+#define DPPM_NOALLOC_MAX_GRAPHS 4096
+int dppm_loss_bce_fwd_bwd_noalloc(const float* score, const float* target, const double* sigma_dev, const float* mask,
+                                  int B, int N, int B_global, double* loss_out, float* dscore, void* stream);
+
 /* VLB loss, forward + gradient: sum over graphs and i != j of sym(KL(q || p)) * mask, with q the true posterior
  * q(A_{t-1}=1 | A_t, A_0) and p the model posterior mix (see dppm_reverse_step_vlb).
  * sched_dev: [B][3] doubles (sigmatilde_t, beta_t, sigmatilde_{t-1} = st - st/t) per graph.
