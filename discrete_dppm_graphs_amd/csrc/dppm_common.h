@@ -38,7 +38,7 @@ inline int check_launch(const char* what) {
 // Opt-in launch timing (bench / profiling only): when enabled, selected launches are bracketed by HIP events on
 // their own stream and summed per kernel class by dppm_prof_end().  Disabled (the default) it costs one branch.
 enum ProfClass { PROF_LINEAR = 0, PROF_PLANE_MM = 1, PROF_WGRAD = 2, PROF_NORM = 3,
-                 PROF_WS_MLP2 = 4, PROF_WS_SUM2 = 5, PROF_WS_COLS = 6, PROF_NCLASS = 7 };
+                 PROF_WS_MLP2 = 4, PROF_WS_SUM2 = 5, PROF_WS_COLS = 6, PROF_HEAD = 7, PROF_NCLASS = 8 };
 bool prof_enabled();
 void prof_before(hipStream_t st);
 void prof_after(hipStream_t st, int cls, double work, double bytes = 0.0);   // work: algorithmic FLOPs, bytes: algorithmic HBM bytes of the launch

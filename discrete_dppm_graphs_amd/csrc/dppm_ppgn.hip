@@ -12,6 +12,7 @@
 #include "dppm_gemm.h"
 #include "dppm_wstat.h"
 #include "dppm_wsplit.h"
+#include "dppm_head.h"
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
 #include "dppm_planesplit.h"
@@ -30,6 +31,7 @@ struct Layout {
   size_t maskp, inv_norm, cat, u0, R, act, tmp[4];
   size_t hid1, hid2, o1, o2, mm;   // per-layer saves (training): base + l * S
   size_t rstd;                     // [L][B][H]
+  size_t himg;                     // inference, H = 128: bf16 weight fragments of the fused read-out head (dppm_head.h)
   size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to four 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
@@ -67,6 +69,7 @@ Layout make_layout(int B, int N, int H, int L, int training) {
   w.rstd = bump(off, (size_t)L * B * H);
   if (!training) {
     for (int i = 0; i < 4; ++i) w.tmp[i] = bump(off, w.S);
+    w.himg = H == WS_H ? bump(off, head3_wimg_floats(L)) : 0;
   } else {
     w.tmp[3] = bump(off, w.S);   // y
     w.hid1 = bump(off, w.S * L); w.hid2 = bump(off, w.S * L);
@@ -983,6 +986,13 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
                      c.at(w.rstd) + (size_t)l * B * H);
     if (prof_enabled()) prof_after(c.st, PROF_NORM, 2.0 * sizeof(float) * (double)w.S, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
     DPPM_TRY(check_launch("inorm_fwd"));
+  }
+  // split modes, H = 128: layer_cat_lin, after_conv and final_lin in one pass over the layer outputs (dppm_head.h)
+  const bool head_off = getenv("DPPM_DISABLE_HEAD3") != nullptr;   // A/B switch for measurements and tests (read per call)
+  if (use_wstat(H) && !training && prec != DPPM_PREC_F32 && !head_off) {
+    HeadArgs ha{cat, cat_bs, reinterpret_cast<const uint4*>(c.at(w.himg)), pr->cat_w, w.CT, pr->cat_b, pr->after_b, pr->final_w, pr->final_b,
+                logits, B, N, w.ld, P, L};
+    return head3_run(ha, pr->after_w, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
   }
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)
   if (use_wstat(H)) {   // K = 2 + L*128: the layer outputs two at a time through the weight-stationary kernel, [A, sigma I] as a side input

@@ -380,7 +380,7 @@ def mmd_gaussian_emd(h1, h2, sigma=1.0, distance_scaling=1.0):
     return out
 
 
-PROF_CLASSES = ("linear_gemm", "plane_matmul", "wgrad_gemm", "inorm", "wstat_mlp2", "wstat_sum2", "wstat_cols")
+PROF_CLASSES = ("linear_gemm", "plane_matmul", "wgrad_gemm", "inorm", "wstat_mlp2", "wstat_sum2", "wstat_cols", "head")
 
 
 def prof_begin(max_records=200000):

@@ -490,3 +490,27 @@ def test_headline_geometry_vs_float32_oracle(ops, precision, tol):
     got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
     close(got * mask, ref * mask, tol=tol)
     close(got, ref, tol=tol)
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (2, 64, 1), (1, 130, 2), (5, 23, 4)])
+def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
+    """csrc/dppm_head.hip (layer_cat_lin + after_conv + final_lin in one pass, model/ppgn.py:318-333) against the layer-by-layer
+    read-out of the same precision (DPPM_DISABLE_HEAD3=1) on the same inputs: odd and even layer counts, N % 4 != 0 (ld != N),
+    ragged super-tiles, fewer super-tiles than CUs; and against the oracle at the mode's bar."""
+    from oracle import ppgn as op
+    H = 128
+    rng = np.random.default_rng(900 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + L)
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    os.environ["DPPM_DISABLE_HEAD3"] = "1"
+    try:
+        layered, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    finally:
+        del os.environ["DPPM_DISABLE_HEAD3"]
+    close(got, layered, tol=tol)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
