@@ -18,7 +18,7 @@
 
 namespace dppm {
 
-constexpr int HD_THREADS = 512;
+constexpr int HD_THREADS = 1024;             // 8 staging waves + 8 multiplying waves, one workgroup per CU
 #ifndef HD_NT_VAL
 #define HD_NT_VAL 2
 #endif

@@ -1,12 +1,13 @@
 // Fused read-out head of the H = 128 PPGN (see dppm_head.h).
 #include "dppm_head.h"
 #include "dppm_wsplit.h"
+#include <cstdlib>
 
 namespace dppm {
 
 // weight matrices -> per-lane MFMA fragments of bf16 pieces, once per forward call (576 KB for L = 8)
 template <int NS>
-__global__ __launch_bounds__(HD_THREADS) void head_wimg_kernel(const float* __restrict__ cat_w, int ldw, const float* __restrict__ after_w,
+__global__ __launch_bounds__(512) void head_wimg_kernel(const float* __restrict__ cat_w, int ldw, const float* __restrict__ after_w,
                                                                 int L, uint4* __restrict__ wimg) {
   const int src = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, ci = lane & 15, ch = 16 * w + ci;
@@ -73,7 +74,12 @@ __device__ __forceinline__ void hd_mma4_reload(floatx4 (&acc)[4], HdW& W, const 
   }
 }
 
-template <int NS>
+// Roles: waves 0-7 stage (global -> registers -> bf16 images in LDS; up to four tiles in flight per thread, no accumulators),
+// waves 8-15 multiply (weight fragments + accumulators, LDS reads and MFMAs only) and run the epilogue.  Every wave executes
+// the same sequence of barriers: one per X tile, HD_NT + 1 per epilogue.
+// VAR != 0: timing experiments only (wrong results): 1 = weight fragments never reloaded, 2 = multipliers skip the X-tile products,
+// 3 = stagers issue no global loads
+template <int NS, int VAR>
 __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_hd[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
@@ -83,7 +89,8 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   float* Cs = reinterpret_cast<float*>(smem_hd + 4 * BUF);   // [5][128]: cat_w[:,0], cat_w[:,1], cat_b, after_b, final_w
   float* Ls = Cs + 5 * WS_H;                                 // [2][8 waves][64] partial logits
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 3, w = wave & 7;                  // role 0: stager, role 1: multiplier of channels 16 w ..
   const int g = lane >> 4, ci = lane & 15;
   const int P = a.P, L = a.L;
   const int nsp = (P + HD_SP - 1) / HD_SP;                   // super-tiles per graph
@@ -100,120 +107,146 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
     Cs[4 * WS_H + tid] = a.final_w[tid];
   }
   const float fbias = a.final_b[0];
+  const int per_sp = L * HD_NT;                              // X tiles per super-tile
+  const int nq = nloc * per_sp;                              // X tiles of this workgroup, in stream order q = (i * L + s) * HD_NT + t
 
-  const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);   // staging: channels 4 cg .., positions 4 q ..
-  const int oc = 4 * (tid & 15);
+  auto flush = [&](int b, int sp0, int t) {                  // logits of tile t from the 8 multiplier waves' partial sums (threads 0 .. 63)
+    const float* Lb = Ls + (t & 1) * 8 * WS_TP + tid;
+    float v = fbias;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += Lb[k * WS_TP];
+    const int p = sp0 + WS_TP * t + tid;
+    const int row = p / a.ld, col = p - row * a.ld;
+    if (p < P && col < a.N) a.logits[((size_t)b * a.N + row) * a.N + col] = v;
+  };
+
+  if (role == 0) {
+    // ------------------------------------------------------------------------------------------------ stagers
+    const int u512 = tid;                                    // 0 .. 511
+    const unsigned o0 = (unsigned)(4 * (u512 >> 4)) * P + 4 * (u512 & 15);   // channels 4 cg .., positions 4 q ..
+    const int oc = 4 * (u512 & 15);
+    int qi = 0, qs = 0, qt = 0;                              // issue cursor
+    auto issue = [&](HdPre& pre) {                           // unconditional clamped loads of the tile at the cursor
+      const int ii = qi < nloc ? qi : nloc - 1;
+      const int st = rank + ii * G;
+      const int b = __builtin_amdgcn_readfirstlane(st / nsp);
+      int p0 = __builtin_amdgcn_readfirstlane((st - b * nsp) * HD_SP + WS_TP * qt);
+      if (p0 >= P) p0 = 0;                                   // tile beyond the plane (ragged last super-tile): harmless re-read
+      const float* Xt = a.cat + (size_t)b * a.cat_bs + (size_t)(2 + qs * WS_H) * P + p0 + ((p0 + oc < P) ? o0 : 0u);
+      if (VAR != 3) {
+        pre.a = *reinterpret_cast<const float4*>(Xt);
+        pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+        pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+        pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+      } else {
+        pre.a = pre.b = pre.c = pre.d = make_float4((float)qi, (float)qs, (float)qt, 1.f);
+      }
+      if (++qt == HD_NT) { qt = 0; if (++qs == L) { qs = 0; ++qi; } }
+    };
+    int li = 0, ls = 0, lt = 0;                              // landing cursor
+    auto land = [&](const HdPre& pre, int buf) {
+      const int ii = li < nloc ? li : nloc - 1;
+      const int st = rank + ii * G;
+      const int b = st / nsp;
+      const int p0 = (st - b * nsp) * HD_SP + WS_TP * lt;
+      const bool in = li < nloc && p0 + oc < P;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs + buf * BUF, u512);
+      if (++lt == HD_NT) { lt = 0; if (++ls == L) { ls = 0; ++li; } }
+    };
+    HdPre p0s, p1s, p2s, p3s;                                // tile k travels in set k & 3
+    issue(p0s); issue(p1s); issue(p2s); issue(p3s);
+    land(p0s, 0);
+    __syncthreads();                                         // tile 0 is in X buffer 0
+    int left = per_sp;                                       // X tiles until the next epilogue
+    for (int q = 0; q < nq; q += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (q + u < nq) {
+          // tile q+u is being multiplied; its set (u) is free; tile q+u+1 (set (u+1) & 3) lands in buffer (u+1) & 1
+          if (u == 0) { issue(p0s); land(p1s, 1); }
+          else if (u == 1) { issue(p1s); land(p2s, 0); }
+          else if (u == 2) { issue(p2s); land(p3s, 1); }
+          else { issue(p3s); land(p0s, 0); }
+          __syncthreads();
+          if (--left == 0) {                                 // end of a super-tile: the multipliers' epilogue barriers, and the logits
+            left = per_sp;
+            const int i = (q + u) / per_sp;
+            const int st = rank + i * G;
+            const int b = __builtin_amdgcn_readfirstlane(st / nsp);
+            const int sp0 = __builtin_amdgcn_readfirstlane((st - b * nsp) * HD_SP);
+#pragma unroll
+            for (int t = 0; t < HD_NT; ++t) {
+              __syncthreads();
+              if (t > 0 && tid < WS_TP) flush(b, sp0, t - 1);
+            }
+            __syncthreads();
+            if (tid < WS_TP) flush(b, sp0, HD_NT - 1);
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- multipliers
   const W3Addr ad = w3_addr(ci, g);
   const unsigned hbase = ci * 256 + (g & 1) * 8, hchunk = (2 * w + (g >> 1)) ^ ci;   // R slot in the hidden image (dppm_wsplit.h)
   const uint4* wbase = a.wimg + (size_t)w * 2 * 4 * 64 + lane;
-
-  // cursor over the X tiles of this workgroup in stream order: super-tile i, source s, tile t
-  int qi = 0, qs = 0, qt = 0;
-  auto issue = [&](HdPre& pre) {       // unconditional clamped loads of the tile at the cursor, then advance the cursor
-    const int ii = qi < nloc ? qi : nloc - 1;
-    const int st = rank + ii * G;
-    const int b = __builtin_amdgcn_readfirstlane(st / nsp);
-    int p0 = __builtin_amdgcn_readfirstlane((st - b * nsp) * HD_SP + WS_TP * qt);
-    if (p0 >= P) p0 = 0;                                     // tile beyond the plane (ragged last super-tile): harmless re-read
-    const float* Xt = a.cat + (size_t)b * a.cat_bs + (size_t)(2 + qs * WS_H) * P + p0 + ((p0 + oc < P) ? o0 : 0u);
-    pre.a = *reinterpret_cast<const float4*>(Xt);
-    pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
-    pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
-    pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
-    if (++qt == HD_NT) { qt = 0; if (++qs == L) { qs = 0; ++qi; } }
-  };
-  // landing cursor (one tile behind the issue cursor pair): only the validity of the positions matters
-  int li = 0, ls = 0, lt = 0;
-  auto land = [&](const HdPre& pre, int buf) {
-    const int ii = li < nloc ? li : nloc - 1;
-    const int st = rank + ii * G;
-    const int b = st / nsp;
-    const int p0 = (st - b * nsp) * HD_SP + WS_TP * lt;
-    const bool in = li < nloc && p0 + oc < P;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs + buf * BUF, tid);
-    if (++lt == HD_NT) { lt = 0; if (++ls == L) { ls = 0; ++li; } }
-  };
-
   floatx4 acc[HD_NT][4];
-  HdPre preA, preB;
   HdW W;
   hd_load_w<NS>(W, wbase);                                   // phase 0 of the first super-tile
-  issue(preA);
-  land(preA, 0);
-  issue(preB);
-  __syncthreads();
-
-  // one weight phase: ph < L: source ph (four X tiles); ph == L: after_conv + final_lin on the four R tiles
-  auto phase = [&](int i, int ph) {
-    const uint4* wnext = wbase + (size_t)(ph == L ? 0 : ph + 1) * HD_WFRAG;   // next phase's fragments, requested during this phase's last tile
-    if (ph < L) {
-      if (ph == 0) {
+  __syncthreads();                                           // tile 0 is in X buffer 0
+  for (int i = 0; i < nloc; ++i) {
 #pragma unroll
-        for (int t = 0; t < HD_NT; ++t)
+    for (int t = 0; t < HD_NT; ++t)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int j = 0; j < 4; ++j) acc[t][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int ph = 0; ph < L; ++ph) {                         // source ph: HD_NT tiles; tile t of the phase sits in X buffer t & 1 (HD_NT even)
+      const uint4* wnext = wbase + (size_t)(ph + 1) * HD_WFRAG;
 #pragma unroll
-      for (int t = 0; t < HD_NT; ++t) {                      // tile t sits in X buffer t & 1; tile t+1 is in flight in set (t+1) & 1
-        issue((t & 1) ? preB : preA);                        // tile t+2 into the set tile t travelled in
-        if (t < HD_NT - 1) w3_mma4<NS, true>(acc[t], W.h, W.l, Xs + (t & 1) * BUF, ad);
-        else hd_mma4_reload<NS>(acc[t], W, Xs + (t & 1) * BUF, ad, wnext);
-        land((t & 1) ? preA : preB, (t + 1) & 1);
+      for (int t = 0; t < HD_NT; ++t) {
+        if (VAR == 2) { }
+        else if (t < HD_NT - 1 || VAR == 1) w3_mma4<NS, true>(acc[t], W.h, W.l, Xs + (t & 1) * BUF, ad);
+        else hd_mma4_reload<NS>(acc[t], W, Xs + (t & 1) * BUF, ad, wnext);   // next phase's fragments arrive behind the last tile
         __syncthreads();
       }
-      return;
     }
-    // ---- epilogue of super-tile i
+    // ---- epilogue of super-tile i: W holds after_conv
     const int st = rank + i * G;
     const int b = __builtin_amdgcn_readfirstlane(st / nsp);
     const int sp0 = __builtin_amdgcn_readfirstlane((st - b * nsp) * HD_SP);
     const float* side = a.cat + (size_t)b * a.cat_bs;
-    float4 ws0, ws1, cb, ab, fw;                             // the lane's channels 16 w + 4 g + r
-    {
-      const int c4 = 16 * w + 4 * g;
-      ws0 = *reinterpret_cast<const float4*>(Cs + c4);
-      ws1 = *reinterpret_cast<const float4*>(Cs + WS_H + c4);
-      cb = *reinterpret_cast<const float4*>(Cs + 2 * WS_H + c4);
-      ab = *reinterpret_cast<const float4*>(Cs + 3 * WS_H + c4);
-      fw = *reinterpret_cast<const float4*>(Cs + 4 * WS_H + c4);
-    }
-    auto flush = [&](int t) {                                // logits of tile t from the 8 waves' partial sums
-      if (tid < WS_TP) {
-        const float* Lb = Ls + (t & 1) * 8 * WS_TP + tid;
-        float v = fbias;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v += Lb[k * WS_TP];
-        const int p = sp0 + WS_TP * t + tid;
-        const int row = p / a.ld, col = p - row * a.ld;
-        if (p < P && col < a.N) a.logits[((size_t)b * a.N + row) * a.N + col] = v;
-      }
-    };
+    const int c4 = 16 * w + 4 * g;                           // the lane's channels c4 .. c4 + 3
 #pragma unroll
     for (int t = 0; t < HD_NT; ++t) {
       char* Hb = Hs + (t & 1) * BUF;
+      {
+        const float4 ws0 = *reinterpret_cast<const float4*>(Cs + c4), ws1 = *reinterpret_cast<const float4*>(Cs + WS_H + c4);
+        const float4 cb = *reinterpret_cast<const float4*>(Cs + 2 * WS_H + c4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {                          // R = acc + side input + bias -> registers and hidden image
-        const int p = sp0 + WS_TP * t + 16 * j + ci;
-        const int pc = p < P ? p : 0;
-        const float av = side[pc], sv = side[(size_t)P + pc];
-        floatx4& r = acc[t][j];
-        r[0] += ws0.x * av + ws1.x * sv + cb.x; r[1] += ws0.y * av + ws1.y * sv + cb.y;
-        r[2] += ws0.z * av + ws1.z * sv + cb.z; r[3] += ws0.w * av + ws1.w * sv + cb.w;
-        unsigned h01, l01 = 0, h23, l23 = 0;
-        w3_split2<NS>(r[0], r[1], h01, l01);
-        w3_split2<NS>(r[2], r[3], h23, l23);
-        const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
-        *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
-        if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
+        for (int j = 0; j < 4; ++j) {                        // R = acc + side input + bias -> registers and hidden image
+          const int p = sp0 + WS_TP * t + 16 * j + ci;
+          const int pc = p < P ? p : 0;
+          const float av = side[pc], sv = side[(size_t)P + pc];
+          floatx4& r = acc[t][j];
+          r[0] += ws0.x * av + ws1.x * sv + cb.x; r[1] += ws0.y * av + ws1.y * sv + cb.y;
+          r[2] += ws0.z * av + ws1.z * sv + cb.z; r[3] += ws0.w * av + ws1.w * sv + cb.w;
+          unsigned h01, l01 = 0, h23, l23 = 0;
+          w3_split2<NS>(r[0], r[1], h01, l01);
+          w3_split2<NS>(r[2], r[3], h23, l23);
+          const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
+          *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
+          if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
+        }
       }
       __syncthreads();
-      if (t > 0) flush(t - 1);
       floatx4 act[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) act[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (t < HD_NT - 1) w3_mma4<NS, true>(act, W.h, W.l, Hb, ad);
-      else hd_mma4_reload<NS>(act, W, Hb, ad, wnext);
+      if (t < HD_NT - 1 || VAR == 1) w3_mma4<NS, true>(act, W.h, W.l, Hb, ad);
+      else hd_mma4_reload<NS>(act, W, Hb, ad, wbase);        // source 0 of the next super-tile
+      const float4 ab = *reinterpret_cast<const float4*>(Cs + 3 * WS_H + c4), fw = *reinterpret_cast<const float4*>(Cs + 4 * WS_H + c4);
       float part[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -228,32 +261,27 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       Ls[(t & 1) * 8 * WS_TP + w * WS_TP + 16 * g + ci] = mine;
     }
     __syncthreads();
-    flush(HD_NT - 1);
-  };
-
-  for (int i = 0; i < nloc; ++i)
-    for (int ph = 0; ph <= L; ++ph) phase(i, ph);
+  }
 }
 
 template <int NS> inline size_t head3_lds() { return (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + 5 * WS_H * sizeof(float) + 2 * 8 * WS_TP * sizeof(float); }
 
 template <int NS>
 static int head3_launch(const HeadArgs& a, const float* after_w, hipStream_t st) {
-  static bool set = false;
   const size_t lds = head3_lds<NS>();
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(head3_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "head3: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set = true;
-  }
+  const char* ev = getenv("DPPM_HEAD_VARIANT");
+  const int var = ev ? atoi(ev) : 0;
+  auto kern = var == 1 ? head3_kernel<NS, 1> : var == 2 ? head3_kernel<NS, 2> : var == 3 ? head3_kernel<NS, 3> : head3_kernel<NS, 0>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(DPPM_E_LAUNCH, "head3: cannot raise the dynamic LDS limit to %zu bytes", lds);
   if ((long)(2 + a.L * WS_H) * a.P >= (1L << 31)) return fail(DPPM_E_INVALID, "head3: P=%d too large", a.P);
-  hipLaunchKernelGGL(head_wimg_kernel<NS>, dim3(a.L + 1), dim3(HD_THREADS), 0, st, a.cat_w, a.ldw, after_w, a.L, const_cast<uint4*>(a.wimg));
+  hipLaunchKernelGGL(head_wimg_kernel<NS>, dim3(a.L + 1), dim3(512), 0, st, a.cat_w, a.ldw, after_w, a.L, const_cast<uint4*>(a.wimg));
   DPPM_TRY(check_launch("head_wimg"));
   const long total = (long)a.B * ((a.P + HD_SP - 1) / HD_SP);
   const int grid = (int)(total < 256 ? total : 256);     // one workgroup per CU
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  hipLaunchKernelGGL(head3_kernel<NS>, dim3(grid), dim3(HD_THREADS), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(HD_THREADS), lds, st, a);
   if (prof) prof_after(st, PROF_HEAD, 2.0 * WS_H * ((double)a.L * WS_H + 2 + WS_H + 1) * a.P * a.B,
                        sizeof(float) * ((double)a.L * WS_H + 2) * a.P * a.B + sizeof(float) * (double)a.N * a.N * a.B);
   return check_launch("head3");
