@@ -33,6 +33,7 @@ struct HeadArgs {
   const float* cat_b; const float* after_b; const float* final_w; const float* final_b;
   float* logits;                               // [B][N][N]
   int B, N, ld, P, L;
+  const float* aff; const float* maskp;        // nullable: [L][B][2][128] (scale, shift) of each layer's instance norm, mask planes [B][P]
 };
 
 // logits = head(CAT) for H = 128 (dppm_head.hip).  a.wimg: scratch of head3_wimg_floats(L) floats, 16-byte aligned.  ns: 3 = bf16x3, 1 = bf16.

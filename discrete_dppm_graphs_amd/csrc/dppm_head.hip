@@ -22,7 +22,7 @@ __global__ __launch_bounds__(512) void head_wimg_kernel(const float* __restrict_
   }
 }
 
-struct HdPre { float4 a, b, c, d; };            // one X tile in flight per thread (named members: stays in registers)
+struct HdPre { float4 a, b, c, d, sc, sh; };    // one X tile in flight per thread (named members: stays in registers); sc / sh: NRM only
 struct HdW { uintx4 h[4], l[4]; };              // a wave's fragments of one weight phase
 
 template <int NS>
@@ -77,9 +77,9 @@ __device__ __forceinline__ void hd_mma4_reload(floatx4 (&acc)[4], HdW& W, const 
 // Roles: waves 0-7 stage (global -> registers -> bf16 images in LDS; up to four tiles in flight per thread, no accumulators),
 // waves 8-15 multiply (weight fragments + accumulators, LDS reads and MFMAs only) and run the epilogue.  Every wave executes
 // the same sequence of barriers: one per X tile, HD_NT + 1 per epilogue.
-// VAR != 0: timing experiments only (wrong results): 1 = weight fragments never reloaded, 2 = multipliers skip the X-tile products,
-// 3 = stagers issue no global loads
-template <int NS, int VAR>
+// NRM: the layer outputs in CAT are the RAW m4 results; their masked instance norm (a.aff: [L][B][2][128] scale, shift) is applied
+// while staging, and the mask (a.maskp) when the accumulators are finished (a masked u_l is an exact zero: model/ppgn.py:315).
+template <int NS, bool NRM>
 __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_hd[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
@@ -133,13 +133,14 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       int p0 = __builtin_amdgcn_readfirstlane((st - b * nsp) * HD_SP + WS_TP * qt);
       if (p0 >= P) p0 = 0;                                   // tile beyond the plane (ragged last super-tile): harmless re-read
       const float* Xt = a.cat + (size_t)b * a.cat_bs + (size_t)(2 + qs * WS_H) * P + p0 + ((p0 + oc < P) ? o0 : 0u);
-      if (VAR != 3) {
-        pre.a = *reinterpret_cast<const float4*>(Xt);
-        pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
-        pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
-        pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
-      } else {
-        pre.a = pre.b = pre.c = pre.d = make_float4((float)qi, (float)qs, (float)qt, 1.f);
+      pre.a = *reinterpret_cast<const float4*>(Xt);
+      pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+      pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+      pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+      if (NRM) {
+        const float* T = a.aff + ((size_t)qs * a.B + b) * 256 + 4 * (u512 >> 4);
+        pre.sc = *reinterpret_cast<const float4*>(T);
+        pre.sh = *reinterpret_cast<const float4*>(T + 128);
       }
       if (++qt == HD_NT) { qt = 0; if (++qs == L) { qs = 0; ++qi; } }
     };
@@ -151,23 +152,24 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       const int p0 = (st - b * nsp) * HD_SP + WS_TP * lt;
       const bool in = li < nloc && p0 + oc < P;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs + buf * BUF, u512);
+      float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+      if (NRM) { w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w); }
+      w3_tile_store4<NS>(xa, xb, xc, xd, Xs + buf * BUF, u512);
       if (++lt == HD_NT) { lt = 0; if (++ls == L) { ls = 0; ++li; } }
     };
-    HdPre p0s, p1s, p2s, p3s;                                // tile k travels in set k & 3
-    issue(p0s); issue(p1s); issue(p2s); issue(p3s);
+    HdPre p0s, p1s, p2s;                                     // tile k travels in set k % 3, lands in X buffer k & 1
+    issue(p0s); issue(p1s); issue(p2s);
     land(p0s, 0);
     __syncthreads();                                         // tile 0 is in X buffer 0
     int left = per_sp;                                       // X tiles until the next epilogue
-    for (int q = 0; q < nq; q += 4) {
+    for (int q = 0; q < nq; q += 6) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 6; ++u) {
         if (q + u < nq) {
-          // tile q+u is being multiplied; its set (u) is free; tile q+u+1 (set (u+1) & 3) lands in buffer (u+1) & 1
-          if (u == 0) { issue(p0s); land(p1s, 1); }
-          else if (u == 1) { issue(p1s); land(p2s, 0); }
-          else if (u == 2) { issue(p2s); land(p3s, 1); }
-          else { issue(p3s); land(p0s, 0); }
+          // tile q+u is being multiplied: its set (u % 3) is free for tile q+u+3; tile q+u+1 lands in buffer (u+1) & 1
+          if (u % 3 == 0) { issue(p0s); land(p1s, (u + 1) & 1); }
+          else if (u % 3 == 1) { issue(p1s); land(p2s, (u + 1) & 1); }
+          else { issue(p2s); land(p0s, (u + 1) & 1); }
           __syncthreads();
           if (--left == 0) {                                 // end of a super-tile: the multipliers' epilogue barriers, and the logits
             left = per_sp;
@@ -206,8 +208,7 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       const uint4* wnext = wbase + (size_t)(ph + 1) * HD_WFRAG;
 #pragma unroll
       for (int t = 0; t < HD_NT; ++t) {
-        if (VAR == 2) { }
-        else if (t < HD_NT - 1 || VAR == 1) w3_mma4<NS, true>(acc[t], W.h, W.l, Xs + (t & 1) * BUF, ad);
+        if (t < HD_NT - 1) w3_mma4<NS, true>(acc[t], W.h, W.l, Xs + (t & 1) * BUF, ad);
         else hd_mma4_reload<NS>(acc[t], W, Xs + (t & 1) * BUF, ad, wnext);   // next phase's fragments arrive behind the last tile
         __syncthreads();
       }
@@ -230,6 +231,9 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
           const int pc = p < P ? p : 0;
           const float av = side[pc], sv = side[(size_t)P + pc];
           floatx4& r = acc[t][j];
+          if (NRM) {
+            if (!(a.maskp[(size_t)b * P + pc] > 0.f)) r = floatx4{0.f, 0.f, 0.f, 0.f};
+          }
           r[0] += ws0.x * av + ws1.x * sv + cb.x; r[1] += ws0.y * av + ws1.y * sv + cb.y;
           r[2] += ws0.z * av + ws1.z * sv + cb.z; r[3] += ws0.w * av + ws1.w * sv + cb.w;
           unsigned h01, l01 = 0, h23, l23 = 0;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       floatx4 act[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) act[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (t < HD_NT - 1 || VAR == 1) w3_mma4<NS, true>(act, W.h, W.l, Hb, ad);
+      if (t < HD_NT - 1) w3_mma4<NS, true>(act, W.h, W.l, Hb, ad);
       else hd_mma4_reload<NS>(act, W, Hb, ad, wbase);        // source 0 of the next super-tile
       const float4 ab = *reinterpret_cast<const float4*>(Cs + 3 * WS_H + c4), fw = *reinterpret_cast<const float4*>(Cs + 4 * WS_H + c4);
       float part[4];
@@ -269,9 +273,9 @@ template <int NS> inline size_t head3_lds() { return (size_t)4 * (NS > 1 ? 2 : 1
 template <int NS>
 static int head3_launch(const HeadArgs& a, const float* after_w, hipStream_t st) {
   const size_t lds = head3_lds<NS>();
-  const char* ev = getenv("DPPM_HEAD_VARIANT");
-  const int var = ev ? atoi(ev) : 0;
-  auto kern = var == 1 ? head3_kernel<NS, 1> : var == 2 ? head3_kernel<NS, 2> : var == 3 ? head3_kernel<NS, 3> : head3_kernel<NS, 0>;
+  const bool nrm = a.aff != nullptr;
+  if (nrm && !a.maskp) return fail(DPPM_E_INVALID, "head3: the fused instance norm needs the mask planes");
+  auto kern = nrm ? head3_kernel<NS, true> : head3_kernel<NS, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(DPPM_E_LAUNCH, "head3: cannot raise the dynamic LDS limit to %zu bytes", lds);
   if ((long)(2 + a.L * WS_H) * a.P >= (1L << 31)) return fail(DPPM_E_INVALID, "head3: P=%d too large", a.P);

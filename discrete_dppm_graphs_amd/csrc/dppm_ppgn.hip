@@ -32,6 +32,7 @@ struct Layout {
   size_t hid1, hid2, o1, o2, mm;   // per-layer saves (training): base + l * S
   size_t rstd;                     // [L][B][H]
   size_t himg;                     // inference, H = 128: bf16 weight fragments of the fused read-out head (dppm_head.h)
+  size_t nstat, ncnt, naff;        // inference, H = 128: per-tile statistics [B*tpp][128][2], counts [B*tpp], (scale, shift) tables [L+1][B][2][128]
   size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to four 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
@@ -70,6 +71,12 @@ Layout make_layout(int B, int N, int H, int L, int training) {
   if (!training) {
     for (int i = 0; i < 4; ++i) w.tmp[i] = bump(off, w.S);
     w.himg = H == WS_H ? bump(off, head3_wimg_floats(L)) : 0;
+    if (H == WS_H) {
+      const size_t ntiles = (size_t)B * ((w.P + WS_TP - 1) / WS_TP);
+      w.nstat = bump(off, ntiles * WS_H * 2);
+      w.ncnt = bump(off, ntiles);
+      w.naff = bump(off, (size_t)(L + 1) * B * 2 * WS_H);
+    }
   } else {
     w.tmp[3] = bump(off, w.S);   // y
     w.hid1 = bump(off, w.S * L); w.hid2 = bump(off, w.S * L);
@@ -255,6 +262,50 @@ inline void launch_inorm_bwd(int P, int nplanes, hipStream_t st, Args... args) {
   if (nth == 64) hipLaunchKernelGGL(inorm_bwd_kernel<64>, dim3(nplanes), dim3(64), 0, st, args...);
   else if (nth == 256) hipLaunchKernelGGL(inorm_bwd_kernel<256>, dim3(nplanes), dim3(256), 0, st, args...);
   else hipLaunchKernelGGL(inorm_bwd_kernel<NORM_THREADS>, dim3(nplanes), dim3(NORM_THREADS), 0, st, args...);
+}
+
+// Instance norm folded into its producer and consumers (split-bf16 inference, dppm_wsplit.h): the two-source Linear m4 leaves, per
+// 64-position tile and channel, (masked mean, centred sum of squares) and the tile's unmasked count; this kernel merges the tiles
+// of a graph (pairwise update of Chan et al., in double) into (scale, shift) = (rstd, -mean * rstd) with the reference's biased
+// variance and eps = 1e-5 (util/model_helper.py:182-190).  One workgroup per graph: 128 channels x 8 tile groups.
+__global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ stat, const float* __restrict__ cnt, int tpp,
+                                                             float* __restrict__ aff) {
+  __shared__ double sn[8][WS_H], sm[8][WS_H], sq[8][WS_H];
+  const int b = blockIdx.x, c = threadIdx.x & (WS_H - 1), grp = threadIdx.x >> 7;
+  double n = 0.0, mean = 0.0, M2 = 0.0;
+  for (int t = grp; t < tpp; t += 8) {
+    const size_t tile = (size_t)b * tpp + t;
+    const double nt = cnt[tile];
+    if (nt > 0.0) {
+      const float2 s = *reinterpret_cast<const float2*>(stat + (tile * WS_H + c) * 2);
+      const double d = (double)s.x - mean, tot = n + nt;
+      mean += d * nt / tot;
+      M2 += (double)s.y + d * d * n * nt / tot;
+      n = tot;
+    }
+  }
+  sn[grp][c] = n; sm[grp][c] = mean; sq[grp][c] = M2;
+  __syncthreads();
+  if (grp == 0) {
+    for (int k = 1; k < 8; ++k) {
+      const double nt = sn[k][c];
+      if (nt > 0.0) {
+        const double d = sm[k][c] - mean, tot = n + nt;
+        mean += d * nt / tot;
+        M2 += sq[k][c] + d * d * n * nt / tot;
+        n = tot;
+      }
+    }
+    const float var = n > 0.0 ? (float)(M2 / n) : 0.f;
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    aff[(size_t)b * 2 * WS_H + c] = rstd;
+    aff[(size_t)b * 2 * WS_H + WS_H + c] = (float)(-mean) * rstd;
+  }
+}
+// the identity table (layer 0's skip input u0 is not normalised)
+__global__ __launch_bounds__(256) void aff_identity_kernel(float* __restrict__ aff, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) aff[i] = (i & 255) < WS_H ? 1.f : 0.f;
 }
 
 // Powerful_Ind conditioning: plane[b][i][i] = cond[b] for i < N on the (all-zero) pad channel of a layer's input
@@ -700,11 +751,12 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
 
 // m1, m2: Linear -> LeakyReLU -> Linear, then * mask   (model/ppgn.py:58-59)
 int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long x_bs, const float* maskp, float* o1, float* o2,
-             float* hid1, float* hid2, bool save_hid, int prec) {
+             float* hid1, float* hid2, bool save_hid, int prec, const float* aff = nullptr) {
   const long hs = (long)H * c.P;
   if (use_wstat(H)) {   // weight-stationary fused pair: hidden activations stay in LDS unless training
     WsArgs wa{};
     wa.njobs = 2; wa.maskp = maskp; wa.B = c.B; wa.P = c.P;
+    wa.aff = aff;   // split inference forms only (checked by the caller)
     const float* w0[2] = {q.m1_w0, q.m2_w0}; const float* w1[2] = {q.m1_w1, q.m2_w1};
     const float* b0[2] = {q.m1_b0, q.m2_b0}; const float* b1[2] = {q.m1_b1, q.m2_b1};
     float* out[2] = {o1, o2}; float* hid[2] = {hid1, hid2};
@@ -950,6 +1002,19 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   hipLaunchKernelGGL(inlin_kernel, dim3(cdiv(P, 1024), B), dim3(256), 0, c.st, cat, cat_bs, pr->in_w, pr->in_b, H, P, c.at(w.u0));
   DPPM_TRY(check_launch("in_lin"));
 
+  // Split modes, H = 128: the instance norm has no pass of its own.  m4 writes its raw result into the layer's CAT slot together
+  // with per-tile statistics, norm_finalize_kernel turns them into a (scale, shift) table per graph and channel, and the three
+  // consumers of the layer output (next layer's MLP pair and skip input, read-out head) apply it while staging.
+  const int tpp = (P + WS_TP - 1) / WS_TP;
+  const bool fuse_norm = use_wstat(H) && !training && prec != DPPM_PREC_F32 && !pr->layer_cond && getenv("DPPM_DISABLE_NORMFUSE") == nullptr &&
+                         getenv("DPPM_DISABLE_HEAD3") == nullptr && w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
+                         w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)));
+  float* naff = fuse_norm ? c.at(w.naff) : nullptr;
+  const size_t aff_sz = (size_t)B * 2 * WS_H;
+  if (fuse_norm) {
+    hipLaunchKernelGGL(aff_identity_kernel, dim3(cdiv((long)aff_sz, 256)), dim3(256), 0, c.st, naff + (size_t)L * aff_sz, (int)aff_sz);
+    DPPM_TRY(check_launch("aff_identity"));
+  }
   for (int l = 0; l < L; ++l) {
     const dppm_ppgn_layer& q = pr->layers_host[l];
     const float* x = l == 0 ? c.at(w.u0) : cat + (size_t)(2 + (l - 1) * H) * P;
@@ -965,7 +1030,8 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       hipLaunchKernelGGL(diag_set_kernel, dim3(B), dim3(256), 0, c.st, xin + (size_t)(H - 1) * P, x_bs, N, w.ld, pr->layer_cond + (size_t)l * B);
       DPPM_TRY(check_launch("diag_set"));
     }
-    DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec));
+    DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec,
+                      fuse_norm && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
     DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, prec));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
@@ -975,7 +1041,18 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       WsJob& j = wa.job[0];
       j.X = mm; j.x_bs = hs; j.X2 = x; j.x2_bs = x_bs; j.W1 = q.m4_w; j.W2 = q.m4_w + H; j.ldw1 = 2 * H; j.ldw2 = 2 * H; j.b1 = q.m4_b;
       j.Y = y; j.y_bs = hs;
+      if (fuse_norm) {   // raw result straight into the CAT slot, statistics beside it
+        j.Y = cat + (size_t)(2 + l * H) * P; j.y_bs = cat_bs;
+        wa.aff = naff + (size_t)(l > 0 ? l - 1 : L) * aff_sz;
+        wa.stat = c.at(w.nstat); wa.cnt = c.at(w.ncnt); wa.maskstat = maskp;
+      }
       DPPM_TRY(ws_lin_p(wa, 2, false, prec, c.st));
+      if (fuse_norm) {
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3(B), dim3(1024), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,
+                           naff + (size_t)l * aff_sz);
+        DPPM_TRY(check_launch("norm_finalize"));
+        continue;
+      }
     } else {
       LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
@@ -991,7 +1068,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   const bool head_off = getenv("DPPM_DISABLE_HEAD3") != nullptr;   // A/B switch for measurements and tests (read per call)
   if (use_wstat(H) && !training && prec != DPPM_PREC_F32 && !head_off) {
     HeadArgs ha{cat, cat_bs, reinterpret_cast<const uint4*>(c.at(w.himg)), pr->cat_w, w.CT, pr->cat_b, pr->after_b, pr->final_w, pr->final_b,
-                logits, B, N, w.ld, P, L};
+                logits, B, N, w.ld, P, L, fuse_norm ? naff : nullptr, fuse_norm ? maskp : nullptr};
     return head3_run(ha, pr->after_w, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
   }
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)

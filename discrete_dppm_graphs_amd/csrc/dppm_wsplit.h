@@ -110,6 +110,40 @@ __device__ __forceinline__ void w3_tile_store(const float4 (&r)[4], char* __rest
 // one tile in flight: plain members (no array) so that the set provably stays in registers
 struct W3Pre { float4 a, b, c, d; float m; };
 
+// Tiles of a workgroup.  Default: rank, rank + per_job, ... (neighbouring workgroups stream neighbouring tiles).  CONTIG: one
+// contiguous run per workgroup, so that it crosses a graph boundary at most once per tpp tiles and the per-graph normalisation
+// tables of its whole run (W3_TAB graphs at most, checked on the host) sit in LDS for the launch.
+constexpr int W3_TAB = 4;
+struct W3Tiles { int first, stride, nloc; };
+template <bool CONTIG>
+__device__ __forceinline__ W3Tiles w3_tiles(const WsWho& who, int ntiles) {
+  W3Tiles t;
+  if (CONTIG) {
+    const int chunk = (ntiles + who.per_job - 1) / who.per_job;
+    t.first = who.rank * chunk; t.stride = 1;
+    const int left = ntiles - t.first;
+    t.nloc = left < 0 ? 0 : (left < chunk ? left : chunk);
+  } else {
+    t.first = who.rank; t.stride = who.per_job;
+    t.nloc = who.rank < ntiles ? (ntiles - who.rank + who.per_job - 1) / who.per_job : 0;
+  }
+  return t;
+}
+// host: does every workgroup's contiguous run stay within W3_TAB graphs?
+inline bool w3_contig_ok(long ntiles, int tpp, int per_job) {
+  const long chunk = (ntiles + per_job - 1) / per_job;
+  return (chunk + tpp - 1) / tpp + 1 <= W3_TAB;
+}
+// the (scale, shift) tables of graphs b0 .. b0 + W3_TAB - 1 -> LDS (1024 threads: one float each)
+__device__ __forceinline__ void w3_load_tab(float* __restrict__ Tb, const float* __restrict__ aff, int b0, int B, int tid) {
+  if (tid < W3_TAB * 256) {
+    int b = b0 + (tid >> 8);
+    if (b > B - 1) b = B - 1;
+    Tb[tid] = aff[(size_t)b * 256 + (tid & 255)];
+  }
+}
+__device__ __forceinline__ void w3_affine(float4& v, float sc, float sh) { v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+
 // per-lane byte offsets of the fragment (position 16 j + ci, k = 32 s + 8 g ..): aj[j] ^ (s << 6)
 // (chunk (4s | g) ^ ci ^ j: bits 2-3 are s ^ (ci >> 2), folded into aj as (ci >> 2) << 6, so s enters as one XOR)
 struct W3Addr { unsigned aj[4]; };
@@ -268,7 +302,7 @@ __device__ __forceinline__ void w3_mma2(floatx4 (&acc)[2], const uintx4 (&wh)[4]
 
 // DEPTH = tiles in flight per staging wave (1: 16 registers, 2: 32): the short bf16 stages need 2, the 3-MFMA stages of the
 // split form cover the latency with 1 (and have no registers to spare).
-template <int NS, int DEPTH>
+template <int NS, int DEPTH, bool NRM>
 __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
@@ -276,6 +310,7 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
   char* Xs = smem3;                       // [2][NIMG] images
   char* Hs = smem3 + 2 * BUF;             // [2][NIMG] images
   float* Ms = reinterpret_cast<float*>(smem3 + 4 * BUF);   // [4][64] mask rows: tile i is written in iteration i-1 and read in i+1
+  float* Tb = Ms + 4 * 64;                                 // NRM: [W3_TAB][2][128] (scale, shift) of the graphs this workgroup meets
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 3, w8 = wave & 7;
@@ -283,7 +318,13 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
   const WsWho who = ws_who(a.njobs);
   const WsJob& J = a.job[who.jid];
   const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
-  if (who.rank >= ntiles) return;   // whole workgroup, before any barrier
+  const W3Tiles tl = w3_tiles<NRM>(who, ntiles);
+  if (tl.nloc <= 0) return;   // whole workgroup, before any barrier
+  const int b0 = tl.first / tpp;
+  if (NRM) {                                              // the prologue's first landing already reads the table
+    w3_load_tab(Tb, a.aff, b0, a.B, tid);
+    __syncthreads();
+  }
 
   uintx4 wh[4], wl[4];
   w3_load_w<NS, false>(wh, wl, role ? J.W2 : J.W1, role ? J.ldw2 : J.ldw1, ch, g);
@@ -299,16 +340,16 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
   // stage 1 result slot in the hidden image: position 16 j + ci, k = 16 w8 + 4 g .. +3 (chunk 2 w8 + (g >> 1), half g & 1)
   const unsigned hbase = ci * 256 + (g & 1) * 8, hchunk = (2 * w8 + (g >> 1)) ^ ci;
 
-  // tiles of this workgroup: t_i = rank + i * per_job, i < nloc (>= 1).
+  // tiles of this workgroup: t_i = first + i * stride, i < nloc (>= 1).
   // Every global load below is UNCONDITIONAL straight-line code (indices clamped instead of predicated): a load inside
   // a lane- or loop-dependent branch makes the compiler drain the whole queue (s_waitcnt vmcnt(0)) at the join, which
   // serialises the prefetch with the compute.
-  const int nloc = (ntiles - who.rank + who.per_job - 1) / who.per_job;
+  const int nloc = tl.nloc;
   const float* maskp = a.maskp;
   // Only the stage-1 waves stage tiles: their queue then holds loads only, so the counted waits the compiler emits are
   // exact.  (A wave that also stores would have to drain its just-issued stores before every landing.)
   auto issue = [&](int i, W3Pre& pre) {   // global loads of tile min(i, nloc-1) into a prefetch register set
-    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int t = tl.first + (i < nloc ? i : nloc - 1) * tl.stride;
     const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
     const float* Xt = J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);   // ragged last tile: re-read in-range data, zeroed when landed
     pre.a = *reinterpret_cast<const float4*>(Xt);
@@ -318,11 +359,17 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
     if (maskp) pre.m = maskp[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
   };
   auto land = [&](int i, const W3Pre& pre) {   // register set -> images of buffer i & 1, mask row i & 3
-    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int t = tl.first + (i < nloc ? i : nloc - 1) * tl.stride;
     const int p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
     const bool in = p0 + oc < P;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs + (i & 1) * BUF, tid);
+    float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+    if (NRM) {   // the source's instance norm: channel 4 cg + v of graph b
+      const float* T = Tb + (t / tpp - b0) * 256 + 4 * (tid >> 4);
+      const float4 sc = *reinterpret_cast<const float4*>(T), sh = *reinterpret_cast<const float4*>(T + 128);
+      w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
+    }
+    w3_tile_store4<NS>(xa, xb, xc, xd, Xs + (i & 1) * BUF, tid);
     if (tid < 64) Ms[(i & 3) * 64 + tid] = (p0 + lane < P) ? pre.m : 0.f;
   };
   // one iteration: stage 1 of tile i and stage 2 of tile i-1; tile i + AHEAD is requested into (pi, mi) before the MFMAs,
@@ -349,7 +396,7 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
       }
       land(i + 1, pl);
     } else if (i >= 1) {
-      const int t = who.rank + (i - 1) * who.per_job;
+      const int t = tl.first + (i - 1) * tl.stride;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
       const float* Mb = Ms + ((i - 1) & 3) * 64;
       float* Yt = J.Y + (size_t)b * J.y_bs + p0;
@@ -395,7 +442,13 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
   }
 }
 
-template <int NS> inline size_t w3m_lds() { return (size_t)(NS > 1 ? 8 : 4) * W3_IMG + 4 * 64 * sizeof(float); }
+template <int NS> inline size_t w3m_lds() { return (size_t)(NS > 1 ? 8 : 4) * W3_IMG + 4 * 64 * sizeof(float) + W3_TAB * 256 * sizeof(float); }
+inline long w3_slots(int njobs, long ntiles) {   // workgroups per job and XCD (one workgroup per CU: 32 per XCD)
+  long slots = 32 / njobs;
+  const long need = (ntiles + 7) / 8;
+  if (slots > need) slots = need;
+  return slots < 1 ? 1 : slots;
+}
 
 template <int NS, int DEPTH = (NS > 1 ? 1 : 2)>
 inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
@@ -404,21 +457,22 @@ inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
     if (!a.job[i].W2) return fail(DPPM_E_INVALID, "w3_mlp_forward: job %d lacks its second matrix", i);
     if (a.job[i].accumulate) return fail(DPPM_E_UNSUPPORTED, "w3_mlp_forward: accumulate is not provided");
   }
-  static bool set = false;
+  static bool set[2] = {false, false};
   const size_t lds = w3m_lds<NS>();
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(w3_mlp_kernel<NS, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  const bool nrm = a.aff != nullptr;
+  auto kern = nrm ? w3_mlp_kernel<NS, DEPTH, true> : w3_mlp_kernel<NS, DEPTH, false>;
+  if (!set[nrm]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "w3_mlp_forward: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set = true;
+    set[nrm] = true;
   }
-  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
-  long slots = 32 / a.njobs;                       // one workgroup per CU: 32 per XCD
-  const long need = (ntiles + 7) / 8;
-  if (slots > need) slots = need;
-  if (slots < 1) slots = 1;
+  const int tpp = (a.P + WS_TP - 1) / WS_TP;
+  const long ntiles = (long)a.B * tpp;
+  const long slots = w3_slots(a.njobs, ntiles);
+  if (nrm && !w3_contig_ok(ntiles, tpp, (int)(8 * slots))) return fail(DPPM_E_UNSUPPORTED, "w3_mlp_forward: normalisation tables of a workgroup's tile run exceed LDS");
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(w3_mlp_kernel<NS, DEPTH>), dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
   const int rc = check_launch("w3_mlp_forward");
   if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
   return rc;
@@ -434,7 +488,9 @@ inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
 // epilogue and stores.  Per tile: MFMAs, barrier, [land tile t+1 (requested a whole tile earlier), request tile t+2,
 // epilogue of tile t], barrier.
 // ---------------------------------------------------------------------------------------------------------
-template <int NS>
+// NRM: the second source is staged through its instance norm (a.aff) and the result's per-tile statistics are emitted (a.stat,
+// a.cnt; see WsArgs).
+template <int NS, bool NRM>
 __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
@@ -445,10 +501,18 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
   const int g = lane >> 4, ci = lane & 15, ch = 16 * w8 + ci;
   char* Xs = smem3 + role * BUF;                                         // this group's source images
   float4* Ps = reinterpret_cast<float4*>(smem3 + 2 * BUF) + (w8 * 4) * 64 + lane;   // partial tile: [w8][j][lane] float4
+  float* Ms = reinterpret_cast<float*>(smem3 + 2 * BUF + WS_H * WS_TP * sizeof(float));   // NRM: [2][64] mask rows of tiles i, i+1
+  float* Tb = Ms + 2 * 64;                                                              // NRM: [W3_TAB][2][128] (scale, shift)
   const WsWho who = ws_who(a.njobs);
   const WsJob& J = a.job[who.jid];
   const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
-  if (who.rank >= ntiles) return;   // whole workgroup, before any barrier
+  const W3Tiles tl = w3_tiles<NRM>(who, ntiles);
+  if (tl.nloc <= 0) return;   // whole workgroup, before any barrier
+  const int b0 = tl.first / tpp;
+  if (NRM) {                                              // the prologue's first landing already reads the table
+    w3_load_tab(Tb, a.aff, b0, a.B, tid);
+    __syncthreads();
+  }
 
   uintx4 wh[4], wl[4];
   w3_load_w<NS, false>(wh, wl, role ? J.W2 : J.W1, role ? J.ldw2 : J.ldw1, ch, g);
@@ -462,31 +526,40 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
   const unsigned r0 = (unsigned)ch * P + 4 * g;
   const unsigned m0 = 4 * g;
   const W3Addr ad = w3_addr(ci, g);
-  const int nloc = (ntiles - who.rank + who.per_job - 1) / who.per_job;
+  const int nloc = tl.nloc;
 
   W3Pre pre;
+  pre.m = 0.f;
   auto issue = [&](int i) {   // unconditional, clamped (see w3_mlp_kernel)
-    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int t = tl.first + (i < nloc ? i : nloc - 1) * tl.stride;
     const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
     const float* Xt = Xsrc + (size_t)b * xbs + p0 + ((p0 + oc < P) ? o0 : 0u);
     pre.a = *reinterpret_cast<const float4*>(Xt);
     pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
     pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
     pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+    if (NRM) pre.m = a.maskstat[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
   };
   auto land = [&](int i) {
-    const int t = who.rank + (i < nloc ? i : nloc - 1) * who.per_job;
+    const int t = tl.first + (i < nloc ? i : nloc - 1) * tl.stride;
     const int p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
     const bool in = p0 + oc < P;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    w3_tile_store4<NS>(in ? pre.a : z, in ? pre.b : z, in ? pre.c : z, in ? pre.d : z, Xs, u);
+    float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+    if (NRM && role == 1) {   // the skip input's instance norm: channel 4 cg + v of graph b
+      const float* T = Tb + (t / tpp - b0) * 256 + 4 * (u >> 4);
+      const float4 sc = *reinterpret_cast<const float4*>(T), sh = *reinterpret_cast<const float4*>(T + 128);
+      w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
+    }
+    w3_tile_store4<NS>(xa, xb, xc, xd, Xs, u);
+    if (NRM && tid < 64) Ms[(i & 1) * 64 + tid] = (i < nloc && p0 + lane < P) ? pre.m : 0.f;
   };
   issue(0);
   land(0);
   issue(1);
   __syncthreads();
   for (int i = 0; i < nloc; ++i) {
-    const int t = who.rank + i * who.per_job;
+    const int t = tl.first + i * tl.stride;
     const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t % tpp) * WS_TP);
     floatx4 acc[4];
 #pragma unroll
@@ -518,6 +591,33 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
           }
         }
       }
+      if (NRM) {
+        // statistics of the result over the tile's unmasked positions, two-pass inside the tile: the lane holds 16 positions of
+        // channel ch, the other 48 sit in the lanes that share ci.  Selects, not products: a masked position may hold anything.
+        const float* Mb = Ms + (i & 1) * 64;
+        float4 mk[4];
+        float sum = 0.f, n = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mk[j] = *reinterpret_cast<const float4*>(Mb + m0 + 16 * j);
+          sum += (mk[j].x > 0.f ? acc[j][0] + bv : 0.f) + (mk[j].y > 0.f ? acc[j][1] + bv : 0.f) +
+                 (mk[j].z > 0.f ? acc[j][2] + bv : 0.f) + (mk[j].w > 0.f ? acc[j][3] + bv : 0.f);
+          n += (mk[j].x > 0.f ? 1.f : 0.f) + (mk[j].y > 0.f ? 1.f : 0.f) + (mk[j].z > 0.f ? 1.f : 0.f) + (mk[j].w > 0.f ? 1.f : 0.f);
+        }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        n += __shfl_xor(n, 16, 64); n += __shfl_xor(n, 32, 64);
+        const float mean = n > 0.f ? sum / n : 0.f;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d0 = mk[j].x > 0.f ? acc[j][0] + bv - mean : 0.f, d1 = mk[j].y > 0.f ? acc[j][1] + bv - mean : 0.f;
+          const float d2 = mk[j].z > 0.f ? acc[j][2] + bv - mean : 0.f, d3 = mk[j].w > 0.f ? acc[j][3] + bv - mean : 0.f;
+          q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        if (g == 0) *reinterpret_cast<float2*>(a.stat + ((size_t)t * WS_H + ch) * 2) = make_float2(mean, q);
+        if (tid == 0) a.cnt[t] = n;
+      }
       ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
                    J.accumulate != 0);
     }
@@ -527,19 +627,21 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
 
 template <int NS>
 inline int w3_lin2(const WsArgs& a, hipStream_t st) {
-  static bool set = false;
-  const size_t lds = (size_t)(NS > 1 ? 4 : 2) * W3_IMG + (size_t)WS_H * WS_TP * sizeof(float);
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(w3_lin2_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  static bool set[2] = {false, false};
+  const size_t lds = (size_t)(NS > 1 ? 4 : 2) * W3_IMG + (size_t)WS_H * WS_TP * sizeof(float) + (2 * 64 + W3_TAB * 256) * sizeof(float);
+  const bool nrm = a.stat != nullptr;
+  if (nrm && (!a.cnt || !a.maskstat || !a.aff || a.njobs != 1)) return fail(DPPM_E_INVALID, "w3_lin2: statistics need aff, cnt, maskstat and a single job");
+  auto kern = nrm ? w3_lin2_kernel<NS, true> : w3_lin2_kernel<NS, false>;
+  if (!set[nrm]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "w3_lin2: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set = true;
+    set[nrm] = true;
   }
-  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
-  long slots = 32 / a.njobs;                       // one workgroup per CU: 32 per XCD
-  const long need = (ntiles + 7) / 8;
-  if (slots > need) slots = need;
-  if (slots < 1) slots = 1;
-  hipLaunchKernelGGL(w3_lin2_kernel<NS>, dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
+  const int tpp = (a.P + WS_TP - 1) / WS_TP;
+  const long ntiles = (long)a.B * tpp;
+  const long slots = w3_slots(a.njobs, ntiles);
+  if (nrm && !w3_contig_ok(ntiles, tpp, (int)(8 * slots))) return fail(DPPM_E_UNSUPPORTED, "w3_lin2: normalisation tables of a workgroup's tile run exceed LDS");
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
   return check_launch("w3_lin2");
 }
 
@@ -558,7 +660,7 @@ inline int w3_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   int rc;
   if (nsrc == 1) rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 1, true>, w3_lds<NS>(), a, st, set[0], "w3_lin<1,T>")
                             : ws_launch_kernel(w3_lin_kernel<NS, 1, false>, w3_lds<NS>(), a, st, set[1], "w3_lin<1,N>");
-  else if (!trans && NS > 1) rc = w3_lin2<NS>(a, st);   // the split form of two matrices does not fit one wave's registers
+  else if (!trans && (NS > 1 || a.stat)) rc = w3_lin2<NS>(a, st);   // the split form of two matrices does not fit one wave's registers; the fused-norm form lives there
   else rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 2, true>, w3_lds<NS>(), a, st, set[2], "w3_lin<2,T>")
                   : ws_launch_kernel(w3_lin_kernel<NS, 2, false>, w3_lds<NS>(), a, st, set[3], "w3_lin<2,N>");
   if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));

@@ -58,6 +58,15 @@ struct WsArgs {
   const float* wside; int ldws;       // [128][ldws], columns 0 and 1
   int act;                            // lin: LeakyReLU on the result
   int B, P;
+  // Instance norm folded into producer and consumers (split-bf16 inference kernels, dppm_wsplit.h; null / 0 elsewhere).
+  //   aff:   [B][2][128] (scale, shift) of the masked instance norm of the source planes: the consumer stages x * scale + shift
+  //          (fused MLP: its source X; two-source Linear: its second source X2, the skip input).  Masked positions are NOT zeroed:
+  //          every consumer's result is masked or unobservable there.
+  //   stat:  the two-source Linear also emits, per 64-position tile and output channel, the masked mean and the centred sum of
+  //          squares of its result: stat[tile][128][2], cnt[tile] = number of unmasked positions of the tile (mask from maskstat
+  //          [B][P]); norm_finalize_kernel merges the tiles of a graph into the next aff table.
+  const float* aff;
+  float* stat; float* cnt; const float* maskstat;
 };
 
 __device__ __forceinline__ int ws_hoff(int k) { return k * WS_HP + 16 * (k >> 5); }

@@ -514,3 +514,29 @@ def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (1, 130, 2), (6, 64, 2), (40, 24, 2)])
+def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
+    """Split modes, H = 128: the masked instance norm (util/model_helper.py:176-191) folded into m4's epilogue (per-tile statistics),
+    norm_finalize_kernel and the consumers' staging, against the same forward with the stand-alone norm pass
+    (DPPM_DISABLE_NORMFUSE=1): ragged graphs (masked positions hold unnormalised values inside the fused path and must not leak),
+    several graphs per workgroup run, a batch (40 x N=24) whose tile runs would span too many graphs and falls back by itself."""
+    from oracle import ppgn as op
+    H = 128
+    rng = np.random.default_rng(1200 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 3 * L)
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    os.environ["DPPM_DISABLE_NORMFUSE"] = "1"
+    try:
+        plain, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    finally:
+        del os.environ["DPPM_DISABLE_NORMFUSE"]
+    assert np.isfinite(got).all()
+    close(got, plain, tol=tol)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
