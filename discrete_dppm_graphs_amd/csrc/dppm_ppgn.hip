@@ -266,40 +266,52 @@ inline void launch_inorm_bwd(int P, int nplanes, hipStream_t st, Args... args) {
 
 // Instance norm folded into its producer and consumers (split-bf16 inference, dppm_wsplit.h): the two-source Linear m4 leaves, per
 // 64-position tile and channel, (masked mean, centred sum of squares) and the tile's unmasked count; this kernel merges the tiles
-// of a graph (pairwise update of Chan et al., in double) into (scale, shift) = (rstd, -mean * rstd) with the reference's biased
-// variance and eps = 1e-5 (util/model_helper.py:182-190).  One workgroup per graph: 128 channels x 8 tile groups.
-__global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ stat, const float* __restrict__ cnt, int tpp,
-                                                             float* __restrict__ aff) {
-  __shared__ double sn[8][WS_H], sm[8][WS_H], sq[8][WS_H];
-  const int b = blockIdx.x, c = threadIdx.x & (WS_H - 1), grp = threadIdx.x >> 7;
-  double n = 0.0, mean = 0.0, M2 = 0.0;
-  for (int t = grp; t < tpp; t += 8) {
-    const size_t tile = (size_t)b * tpp + t;
-    const double nt = cnt[tile];
-    if (nt > 0.0) {
-      const float2 s = *reinterpret_cast<const float2*>(stat + (tile * WS_H + c) * 2);
-      const double d = (double)s.x - mean, tot = n + nt;
-      mean += d * nt / tot;
-      M2 += (double)s.y + d * d * n * nt / tot;
-      n = tot;
-    }
+// of a graph into (scale, shift) = (rstd, -mean * rstd) with the reference's biased variance and eps = 1e-5
+// (util/model_helper.py:182-190):  mean = sum n_t mean_t / n,  M2 = sum (M2_t + n_t (mean_t - mean)^2), accumulated in double.
+// One workgroup per (graph, 16 channels): 64 tile groups x 16 channels (a tile's 16 float2 are 128 contiguous bytes).
+constexpr int NF_CH = 16, NF_GRP = 64;
+__global__ __launch_bounds__(NF_CH * NF_GRP) void norm_finalize_kernel(const float* __restrict__ stat, const float* __restrict__ cnt, int tpp,
+                                                                       float* __restrict__ aff) {
+  __shared__ double s0[NF_GRP][NF_CH], s1[NF_GRP][NF_CH];
+  __shared__ double tot_n[NF_CH], tot_m[NF_CH];
+  const int b = blockIdx.x / (WS_H / NF_CH), c0 = (blockIdx.x % (WS_H / NF_CH)) * NF_CH;
+  const int c = threadIdx.x % NF_CH, grp = threadIdx.x / NF_CH;
+  const size_t base = (size_t)b * tpp;
+  // pass 1: n and n * mean
+  double n = 0.0, sm = 0.0;
+  for (int t = grp; t < tpp; t += NF_GRP) {
+    const double nt = cnt[base + t];
+    const float2 s = *reinterpret_cast<const float2*>(stat + ((base + t) * WS_H + c0 + c) * 2);
+    n += nt;
+    sm += nt > 0.0 ? nt * (double)s.x : 0.0;
   }
-  sn[grp][c] = n; sm[grp][c] = mean; sq[grp][c] = M2;
+  s0[grp][c] = n; s1[grp][c] = sm;
   __syncthreads();
   if (grp == 0) {
-    for (int k = 1; k < 8; ++k) {
-      const double nt = sn[k][c];
-      if (nt > 0.0) {
-        const double d = sm[k][c] - mean, tot = n + nt;
-        mean += d * nt / tot;
-        M2 += sq[k][c] + d * d * n * nt / tot;
-        n = tot;
-      }
-    }
-    const float var = n > 0.0 ? (float)(M2 / n) : 0.f;
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = 0; k < NF_GRP; ++k) { a0 += s0[k][c]; a1 += s1[k][c]; }
+    tot_n[c] = a0; tot_m[c] = a0 > 0.0 ? a1 / a0 : 0.0;
+  }
+  __syncthreads();
+  const double mean = tot_m[c];
+  // pass 2: centred sum of squares about the graph's mean
+  double m2 = 0.0;
+  for (int t = grp; t < tpp; t += NF_GRP) {
+    const double nt = cnt[base + t];
+    const float2 s = *reinterpret_cast<const float2*>(stat + ((base + t) * WS_H + c0 + c) * 2);
+    const double d = (double)s.x - mean;
+    m2 += nt > 0.0 ? (double)s.y + nt * d * d : 0.0;
+  }
+  s0[grp][c] = m2;
+  __syncthreads();
+  if (grp == 0) {
+    double a0 = 0.0;
+    for (int k = 0; k < NF_GRP; ++k) a0 += s0[k][c];
+    const double nn = tot_n[c];
+    const float var = nn > 0.0 ? (float)(a0 / nn) : 0.f;
     const float rstd = 1.f / sqrtf(var + 1e-5f);
-    aff[(size_t)b * 2 * WS_H + c] = rstd;
-    aff[(size_t)b * 2 * WS_H + WS_H + c] = (float)(-mean) * rstd;
+    aff[(size_t)b * 2 * WS_H + c0 + c] = rstd;
+    aff[(size_t)b * 2 * WS_H + WS_H + c0 + c] = (float)(-mean) * rstd;
   }
 }
 // the identity table (layer 0's skip input u0 is not normalised)
@@ -1045,10 +1057,11 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         j.Y = cat + (size_t)(2 + l * H) * P; j.y_bs = cat_bs;
         wa.aff = naff + (size_t)(l > 0 ? l - 1 : L) * aff_sz;
         wa.stat = c.at(w.nstat); wa.cnt = c.at(w.ncnt); wa.maskstat = maskp;
+        { const char* e = getenv("DPPM_DBG"); wa.dbg = e ? atoi(e) : 0; }
       }
       DPPM_TRY(ws_lin_p(wa, 2, false, prec, c.st));
       if (fuse_norm) {
-        hipLaunchKernelGGL(norm_finalize_kernel, dim3(B), dim3(1024), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3(B * (WS_H / NF_CH)), dim3(NF_CH * NF_GRP), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,
                            naff + (size_t)l * aff_sz);
         DPPM_TRY(check_launch("norm_finalize"));
         continue;

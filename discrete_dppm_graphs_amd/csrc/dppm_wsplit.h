@@ -546,7 +546,7 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
     const bool in = p0 + oc < P;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
-    if (NRM && role == 1) {   // the skip input's instance norm: channel 4 cg + v of graph b
+    if (NRM && role == 1 && !(a.dbg & 2)) {   // the skip input's instance norm: channel 4 cg + v of graph b
       const float* T = Tb + (t / tpp - b0) * 256 + 4 * (u >> 4);
       const float4 sc = *reinterpret_cast<const float4*>(T), sh = *reinterpret_cast<const float4*>(T + 128);
       w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
@@ -591,30 +591,33 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
           }
         }
       }
-      if (NRM) {
-        // statistics of the result over the tile's unmasked positions, two-pass inside the tile: the lane holds 16 positions of
-        // channel ch, the other 48 sit in the lanes that share ci.  Selects, not products: a masked position may hold anything.
+      if (NRM && !(a.dbg & 1)) {
+        // statistics of the result over the tile's unmasked positions: the lane holds 16 positions of channel ch, the other 48
+        // sit in the lanes that share ci.  One pass about a pivot that lies inside the data (the channel's value at the tile's first
+        // position, or the bias if that position is masked), so that S2 - S1^2 / n loses no digits to a large mean; three sums,
+        // two shuffle stages.  Selects, not products: a masked position may hold anything.
         const float* Mb = Ms + (i & 1) * 64;
-        float4 mk[4];
-        float sum = 0.f, n = 0.f;
+        const float first = __shfl(acc[0][0], ci, 64) + bv;          // lane (g = 0, ci): position 0 of the tile
+        const float piv = Mb[0] > 0.f ? first : bv;
+        float s1 = 0.f, s2 = 0.f, n = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          mk[j] = *reinterpret_cast<const float4*>(Mb + m0 + 16 * j);
-          sum += (mk[j].x > 0.f ? acc[j][0] + bv : 0.f) + (mk[j].y > 0.f ? acc[j][1] + bv : 0.f) +
-                 (mk[j].z > 0.f ? acc[j][2] + bv : 0.f) + (mk[j].w > 0.f ? acc[j][3] + bv : 0.f);
-          n += (mk[j].x > 0.f ? 1.f : 0.f) + (mk[j].y > 0.f ? 1.f : 0.f) + (mk[j].z > 0.f ? 1.f : 0.f) + (mk[j].w > 0.f ? 1.f : 0.f);
+          const float4 mk = *reinterpret_cast<const float4*>(Mb + m0 + 16 * j);
+          const float d0 = mk.x > 0.f ? acc[j][0] + bv - piv : 0.f, d1 = mk.y > 0.f ? acc[j][1] + bv - piv : 0.f;
+          const float d2 = mk.z > 0.f ? acc[j][2] + bv - piv : 0.f, d3 = mk.w > 0.f ? acc[j][3] + bv - piv : 0.f;
+          s1 += (d0 + d1) + (d2 + d3);
+          s2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+          n += (mk.x > 0.f ? 1.f : 0.f) + (mk.y > 0.f ? 1.f : 0.f) + (mk.z > 0.f ? 1.f : 0.f) + (mk.w > 0.f ? 1.f : 0.f);
         }
-        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
-        n += __shfl_xor(n, 16, 64); n += __shfl_xor(n, 32, 64);
-        const float mean = n > 0.f ? sum / n : 0.f;
-        float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d0 = mk[j].x > 0.f ? acc[j][0] + bv - mean : 0.f, d1 = mk[j].y > 0.f ? acc[j][1] + bv - mean : 0.f;
-          const float d2 = mk[j].z > 0.f ? acc[j][2] + bv - mean : 0.f, d3 = mk[j].w > 0.f ? acc[j][3] + bv - mean : 0.f;
-          q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        for (int o = 16; o <= 32; o <<= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+          n += __shfl_xor(n, o, 64);
         }
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        const float dm = s1 * __builtin_amdgcn_rcpf(fmaxf(n, 1.f));   // mean - pivot
+        const float mean = piv + dm;
+        const float q = fmaxf(s2 - s1 * dm, 0.f);
         if (g == 0) *reinterpret_cast<float2*>(a.stat + ((size_t)t * WS_H + ch) * 2) = make_float2(mean, q);
         if (tid == 0) a.cnt[t] = n;
       }

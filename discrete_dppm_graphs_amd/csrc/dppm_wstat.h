@@ -67,6 +67,7 @@ struct WsArgs {
   //          [B][P]); norm_finalize_kernel merges the tiles of a graph into the next aff table.
   const float* aff;
   float* stat; float* cnt; const float* maskstat;
+  int dbg;                            // timing experiments (DPPM_DBG): bit 0 skips the statistics, bit 1 the affine staging
 };
 
 __device__ __forceinline__ int ws_hoff(int k) { return k * WS_HP + 16 * (k >> 5); }

@@ -492,7 +492,7 @@ def test_headline_geometry_vs_float32_oracle(ops, precision, tol):
     close(got, ref, tol=tol)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 2e-2)])   # two split-precision evaluations, each ~1e-5 from the exact result
 @pytest.mark.parametrize("B,N,L", [(3, 41, 3), (2, 64, 1), (1, 130, 2), (5, 23, 4)])
 def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
     """csrc/dppm_head.hip (layer_cat_lin + after_conv + final_lin in one pass, model/ppgn.py:318-333) against the layer-by-layer
@@ -516,7 +516,7 @@ def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 3e-2)])
 @pytest.mark.parametrize("B,N,L", [(3, 41, 3), (1, 130, 2), (6, 64, 2), (40, 24, 2)])
 def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
     """Split modes, H = 128: the masked instance norm (util/model_helper.py:176-191) folded into m4's epilogue (per-tile statistics),
