@@ -14,7 +14,7 @@ from collections import defaultdict
 CLASS_OF = (("ws_mlp_kernel", "wstat_mlp2"), ("w3_mlp_kernel", "wstat_mlp2"), ("ws_lin_kernel<2", "wstat_sum2"), ("w3_lin2_kernel", "wstat_sum2"),
             ("w3_lin_kernel<3, 2", "wstat_sum2"), ("w3_lin_kernel<1, 2", "wstat_sum2"), ("ws_lin_kernel<1", "wstat_cols"),
             ("w3_lin_kernel<3, 1", "wstat_cols"), ("w3_lin_kernel<1, 1", "wstat_cols"),
-            ("plane_mm", "plane_matmul"), ("plane3_kernel", "plane_matmul"), ("inorm_fwd", "inorm"), ("gemm_f32_kernel", "linear_gemm"))
+            ("plane_mm", "plane_matmul"), ("plane3_kernel", "plane_matmul"), ("plane3h_kernel", "plane_matmul"), ("head3_kernel", "head"), ("inorm_fwd", "inorm"), ("gemm_f32_kernel", "linear_gemm"))
 
 
 def per_kernel(path, counter):
@@ -46,7 +46,7 @@ def main():
             continue
         n = sum(v["launches"] for _, v in sel)
         by_class[cls] = sum(v["hbm_bytes_per_launch"] * v["launches"] for _, v in sel) / max(n, 1)
-    json.dump({"geometry": {"nodes": int(N), "hidden": int(H), "layers": int(L), "graphs_per_gpu": int(B)},
+    json.dump({"geometry": {"nodes": int(N), "hidden": int(H), "layers": int(L), "graphs_per_gpu": int(B)}, "precision": "bf16x3",
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged over launches (gfx950 correction: FETCH_SIZE counts half of wide streaming reads)",
                "bytes_per_launch": by_class, "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in by_class.items():
