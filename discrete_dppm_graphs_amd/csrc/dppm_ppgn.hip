@@ -13,6 +13,7 @@
 #include "dppm_wstat.h"
 #include "dppm_wsplit.h"
 #include "dppm_head.h"
+#include "dppm_w4.h"
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
 #include "dppm_planesplit.h"
@@ -1059,6 +1060,10 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         wa.stat = c.at(w.nstat); wa.cnt = c.at(w.ncnt); wa.maskstat = maskp;
         { const char* e = getenv("DPPM_DBG"); wa.dbg = e ? atoi(e) : 0; }
       }
+      // split inference modes: staging waves / multiplying waves (dppm_w4.hip); DPPM_DISABLE_W4=1 keeps the two-role form of dppm_wsplit.h
+      if (!training && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_lin2_ok(wa))
+        DPPM_TRY(w4_lin2_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st));
+      else
       DPPM_TRY(ws_lin_p(wa, 2, false, prec, c.st));
       if (fuse_norm) {
         hipLaunchKernelGGL(norm_finalize_kernel, dim3(B * (WS_H / NF_CH)), dim3(NF_CH * NF_GRP), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,

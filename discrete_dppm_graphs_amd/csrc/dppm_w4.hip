@@ -1,0 +1,174 @@
+// Role-split forms of the split-bf16 H = 128 linears (see dppm_w4.h): staging waves and multiplying waves.
+//
+// The kernels of dppm_wsplit.h let every wave both stage tiles (global -> registers -> bf16 hi / lo images in LDS) and multiply
+// them: at 128 registers per wave that leaves room for one tile in flight per thread, and every wait for it sits on the path of
+// the MFMAs.  Here waves 0-7 only stage -- three tiles in flight per thread, plus the (scale, shift) pair of the fused instance
+// norm, no accumulators, no weights -- and waves 8-15 only multiply: both weight matrices' fragments stay in 64 registers, the
+// X fragments come from LDS, results go out with 16-byte stores.  One barrier per staged tile keeps the two groups one tile
+// apart; the stagers' loads never wait for a multiplier and the multipliers never wait for HBM.
+#include "dppm_w4.h"
+#include "dppm_wsplit.h"
+
+namespace dppm {
+
+constexpr int W4_THREADS = 1024;
+
+struct W4Pre { float4 a, b, c, d, sc, sh; float m; };   // one tile in flight per staging thread (named members: registers)
+
+// Y = W1 X1 + W2 norm(X2) + b per 64-position tile (model/ppgn.py:66-69: m4 on cat(mm, x)); NRM: X2 is staged through its instance
+// norm (a.aff) and the result's masked per-tile statistics are written (a.stat, a.cnt), see WsArgs in dppm_wstat.h.
+// X tiles in stream order: q = 2 i + s (tile i of this workgroup, source s); tile q travels in register set q % 3 and lands in
+// LDS buffer q & 1.
+template <int NS, bool NRM>
+__global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int BUF = NIMG * W3_IMG;
+  char* Xs = smem4;                                          // [2][BUF]
+  float* Ms = reinterpret_cast<float*>(smem4 + 2 * BUF);     // [2][64] mask rows of position tiles i, i + 1 (NRM)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 3, w8 = wave & 7;
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * w8 + ci;
+  const WsJob& J = a.job[0];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+  const int rank = blockIdx.x, G = gridDim.x;
+  if (rank >= ntiles) return;                                // whole workgroup, before any barrier
+  const int nloc = (ntiles - rank + G - 1) / G;              // position tiles of this workgroup: rank + i * G
+  const int nq = 2 * nloc;
+
+  if (role == 0) {
+    // ------------------------------------------------------------------------------------------------ stagers
+    const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);   // channels 4 cg .., positions 4 q ..
+    const int oc = 4 * (tid & 15);
+    int qi = 0, qs = 0;                                      // issue cursor (tile, source)
+    auto issue = [&](W4Pre& pre) {                           // unconditional clamped loads of the tile at the cursor
+      const int t = rank + (qi < nloc ? qi : nloc - 1) * G;
+      const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
+      const float* Xt = (qs ? J.X2 + (size_t)b * J.x2_bs : J.X + (size_t)b * J.x_bs) + p0 + ((p0 + oc < P) ? o0 : 0u);
+      pre.a = *reinterpret_cast<const float4*>(Xt);
+      pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+      pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+      pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+      if (NRM) {
+        const float* T = a.aff + (size_t)b * 256 + 4 * (tid >> 4);
+        pre.sc = *reinterpret_cast<const float4*>(T);
+        pre.sh = *reinterpret_cast<const float4*>(T + 128);
+        pre.m = a.maskstat[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
+      }
+      if (++qs == 2) { qs = 0; ++qi; }
+    };
+    int li = 0, ls = 0;                                      // landing cursor
+    auto land = [&](const W4Pre& pre, int buf) {
+      const int t = rank + (li < nloc ? li : nloc - 1) * G;
+      const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
+      const bool in = li < nloc && p0 + oc < P;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+      if (NRM && ls == 1) {                                  // the skip input's instance norm (uniform branch)
+        w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w);
+      }
+      w3_tile_store4<NS>(xa, xb, xc, xd, Xs + buf * BUF, tid);
+      if (NRM && ls == 0 && tid < 64) Ms[(li & 1) * 64 + tid] = (li < nloc && p0 + lane < P) ? pre.m : 0.f;
+      if (++ls == 2) { ls = 0; ++li; }
+    };
+    W4Pre p0s, p1s, p2s;
+    issue(p0s); issue(p1s); issue(p2s);
+    land(p0s, 0);
+    __syncthreads();                                         // tile 0 is in buffer 0
+    for (int q = 0; q < nq; q += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        if (q + u < nq) {
+          // tile q+u is being multiplied: its set (u % 3) is free for tile q+u+3; tile q+u+1 lands in buffer (u+1) & 1
+          if (u % 3 == 0) { issue(p0s); land(p1s, (u + 1) & 1); }
+          else if (u % 3 == 1) { issue(p1s); land(p2s, (u + 1) & 1); }
+          else { issue(p2s); land(p0s, (u + 1) & 1); }
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- multipliers
+  uintx4 w1h[4], w1l[4], w2h[4], w2l[4];
+  w3_load_w<NS, false>(w1h, w1l, J.W1, J.ldw1, ch, g);
+  w3_load_w<NS, false>(w2h, w2l, J.W2, J.ldw2, ch, g);
+  const float bv = J.b1 ? J.b1[ch] : 0.f;
+  const W3Addr ad = w3_addr(ci, g);
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+  __syncthreads();                                           // tile 0 is in buffer 0
+  for (int i = 0; i < nloc; ++i) {
+    const int t = rank + i * G;
+    const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
+    floatx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    w3_mma4<NS, false>(acc, w1h, w1l, Xs, ad);
+    __syncthreads();
+    w3_mma4<NS, false>(acc, w2h, w2l, Xs + BUF, ad);
+    if (NRM) {
+      // masked statistics of the result over the tile (one pass about a pivot inside the data, see w3_lin2_kernel)
+      const float* Mb = Ms + (i & 1) * 64;
+      const float first = __shfl(acc[0][0], ci, 64) + bv;
+      const float piv = Mb[0] > 0.f ? first : bv;
+      float s1 = 0.f, s2 = 0.f, n = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 mk = *reinterpret_cast<const float4*>(Mb + m0 + 16 * j);
+        const float d0 = mk.x > 0.f ? acc[j][0] + bv - piv : 0.f, d1 = mk.y > 0.f ? acc[j][1] + bv - piv : 0.f;
+        const float d2 = mk.z > 0.f ? acc[j][2] + bv - piv : 0.f, d3 = mk.w > 0.f ? acc[j][3] + bv - piv : 0.f;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        n += (mk.x > 0.f ? 1.f : 0.f) + (mk.y > 0.f ? 1.f : 0.f) + (mk.z > 0.f ? 1.f : 0.f) + (mk.w > 0.f ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+        n += __shfl_xor(n, o, 64);
+      }
+      const float dm = s1 * __builtin_amdgcn_rcpf(fmaxf(n, 1.f));
+      if (g == 0) *reinterpret_cast<float2*>(a.stat + ((size_t)t * WS_H + ch) * 2) = make_float2(piv + dm, fmaxf(s2 - s1 * dm, 0.f));
+      if (w8 == 0 && lane == 0) a.cnt[t] = n;
+    }
+    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, nullptr, m0, P - p0, bv, false, false);
+    __syncthreads();
+  }
+}
+
+template <int NS>
+static int w4_lin2_launch(const WsArgs& a, hipStream_t st) {
+  static bool set[2] = {false, false};
+  const size_t lds = (size_t)2 * (NS > 1 ? 2 : 1) * W3_IMG + 2 * 64 * sizeof(float);
+  const bool nrm = a.stat != nullptr;
+  auto kern = nrm ? w4_lin2_kernel<NS, true> : w4_lin2_kernel<NS, false>;
+  if (!set[nrm]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "w4_lin2: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    set[nrm] = true;
+  }
+  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
+  const int grid = (int)(ntiles < 256 ? ntiles : 256);       // one workgroup per CU
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), lds, st, a);
+  if (prof) prof_after(st, PROF_WS_SUM2, 4.0 * WS_H * WS_H * (double)a.P * a.B, ws_alg_bytes(a, 2, false, false));
+  return check_launch("w4_lin2");
+}
+
+bool w4_lin2_ok(const WsArgs& a) {
+  const WsJob& j = a.job[0];
+  return a.njobs == 1 && !a.side && !a.act && !a.maskp && !j.accumulate && j.X && j.X2 && j.W1 && j.W2 && j.Y && ws_al16(j.X) && ws_al16(j.X2) &&
+         ws_al16(j.Y) && j.x_bs % 4 == 0 && j.x2_bs % 4 == 0 && j.y_bs % 4 == 0 && a.P % 4 == 0 && (long)WS_H * a.P < (1L << 31) &&
+         (a.stat == nullptr || (a.aff && a.cnt && a.maskstat));
+}
+
+int w4_lin2_run(const WsArgs& a, int ns, hipStream_t st) {
+  if (!w4_lin2_ok(a)) return fail(DPPM_E_INVALID, "w4_lin2: unsupported arguments");
+  return ns == 3 ? w4_lin2_launch<3>(a, st) : w4_lin2_launch<1>(a, st);
+}
+
+}  // namespace dppm
