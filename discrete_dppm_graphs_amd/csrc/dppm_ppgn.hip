@@ -315,6 +315,11 @@ __global__ __launch_bounds__(NF_CH * NF_GRP) void norm_finalize_kernel(const flo
     aff[(size_t)b * 2 * WS_H + WS_H + c0 + c] = (float)(-mean) * rstd;
   }
 }
+// debug (DPPM_DBG & 4): the table from the standalone pass's own statistics
+__global__ __launch_bounds__(256) void aff_from_stats_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ aff, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (b, c)
+  if (i < n) { const int b = i / WS_H, c = i % WS_H; aff[(size_t)b * 2 * WS_H + c] = rstd[i]; aff[(size_t)b * 2 * WS_H + WS_H + c] = -mean[i] * rstd[i]; }
+}
 // the identity table (layer 0's skip input u0 is not normalised)
 __global__ __launch_bounds__(256) void aff_identity_kernel(float* __restrict__ aff, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -778,6 +783,9 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
       j.X = x; j.x_bs = x_bs; j.W1 = w0[k]; j.W2 = w1[k]; j.ldw1 = H; j.ldw2 = H; j.b1 = b0[k]; j.b2 = b1[k];
       j.Mid = save_hid ? hid[k] : nullptr; j.mid_bs = hs; j.Y = out[k]; j.y_bs = hs;
     }
+    // split inference modes: staging waves / multiplying waves (dppm_w4.hip); DPPM_DISABLE_W4=1 keeps the forms of dppm_wsplit.h
+    if (!save_hid && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && getenv("DPPM_W4MLP") != nullptr && w4_mlp_ok(wa))
+      return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
     if (!save_hid && prec == DPPM_PREC_BF16X3) return w3_mlp_forward<3>(wa, c.st);
     if (!save_hid && prec == DPPM_PREC_BF16) return w3_mlp_forward<1>(wa, c.st);
     return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
@@ -1020,8 +1028,10 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   // consumers of the layer output (next layer's MLP pair and skip input, read-out head) apply it while staging.
   const int tpp = (P + WS_TP - 1) / WS_TP;
   const bool fuse_norm = use_wstat(H) && !training && prec != DPPM_PREC_F32 && !pr->layer_cond && getenv("DPPM_DISABLE_NORMFUSE") == nullptr &&
-                         getenv("DPPM_DISABLE_HEAD3") == nullptr && w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
-                         w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)));
+                         getenv("DPPM_DISABLE_HEAD3") == nullptr &&
+                         ((getenv("DPPM_DISABLE_W4") == nullptr && getenv("DPPM_W4MLP") != nullptr) ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
+                          (w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
+                           w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)))));
   float* naff = fuse_norm ? c.at(w.naff) : nullptr;
   const size_t aff_sz = (size_t)B * 2 * WS_H;
   if (fuse_norm) {
@@ -1069,6 +1079,11 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         hipLaunchKernelGGL(norm_finalize_kernel, dim3(B * (WS_H / NF_CH)), dim3(NF_CH * NF_GRP), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,
                            naff + (size_t)l * aff_sz);
         DPPM_TRY(check_launch("norm_finalize"));
+        if (wa.dbg & 4) {
+          launch_inorm_fwd(P, B * H, c.st, (const float*)(cat + (size_t)(2 + l * H) * P), cat_bs, (const float*)maskp, y, hs, H, P, c.at(w.nstat), c.at(w.nstat) + B * H);
+          hipLaunchKernelGGL(aff_from_stats_kernel, dim3((B * H + 255) / 256), dim3(256), 0, c.st, (const float*)c.at(w.nstat), (const float*)(c.at(w.nstat) + B * H),
+                             naff + (size_t)l * aff_sz, B * H);
+        }
         continue;
       }
     } else {

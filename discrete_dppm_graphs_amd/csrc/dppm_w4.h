@@ -9,4 +9,9 @@ namespace dppm {
 bool w4_lin2_ok(const WsArgs& a);
 int w4_lin2_run(const WsArgs& a, int ns, hipStream_t st);
 
+// Fused per-position MLP (Linear -> LeakyReLU -> Linear, * mask) for every job (model/ppgn.py:58-59), hidden tile in LDS;
+// a.aff (nullable): the source's instance norm, applied while staging.
+bool w4_mlp_ok(const WsArgs& a);
+int w4_mlp_run(const WsArgs& a, int ns, hipStream_t st);
+
 }  // namespace dppm

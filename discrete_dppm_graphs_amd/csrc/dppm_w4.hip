@@ -15,6 +15,29 @@ constexpr int W4_THREADS = 1024;
 
 struct W4Pre { float4 a, b, c, d, sc, sh; float m; };   // one tile in flight per staging thread (named members: registers)
 
+// w3_mma4 with the LDS fragment reads one (k step, position group) ahead of the MFMAs that use them: a multiplying wave shares its
+// SIMD with one other multiplier only, so the read latency has to be covered inside the wave (8 more registers).
+template <int NS, bool W_IS_A>
+__device__ __forceinline__ void w4_mma4(floatx4 (&acc)[4], const uintx4 (&wh)[4], const uintx4 (&wl)[4], const char* __restrict__ T, const W3Addr& ad) {
+  uintx4 xh = *reinterpret_cast<const uintx4*>(T + w3_off(ad, 0, 0)), xl = xh;
+  if (NS > 1) xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, 0, 0));
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    const int s = n >> 2, j = n & 3;
+    const uintx4 ch_ = xh, cl_ = xl;
+    if (n + 1 < 16) {
+      const unsigned off = w3_off(ad, (n + 1) & 3, (n + 1) >> 2);
+      xh = *reinterpret_cast<const uintx4*>(T + off);
+      if (NS > 1) xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
+    }
+    if (NS > 1) {
+      acc[j] = W_IS_A ? w3_mfma(wh[s], cl_, acc[j]) : w3_mfma(cl_, wh[s], acc[j]);
+      acc[j] = W_IS_A ? w3_mfma(wl[s], ch_, acc[j]) : w3_mfma(ch_, wl[s], acc[j]);
+    }
+    acc[j] = W_IS_A ? w3_mfma(wh[s], ch_, acc[j]) : w3_mfma(ch_, wh[s], acc[j]);
+  }
+}
+
 // Y = W1 X1 + W2 norm(X2) + b per 64-position tile (model/ppgn.py:66-69: m4 on cat(mm, x)); NRM: X2 is staged through its instance
 // norm (a.aff) and the result's masked per-tile statistics are written (a.stat, a.cnt), see WsArgs in dppm_wstat.h.
 // X tiles in stream order: q = 2 i + s (tile i of this workgroup, source s); tile q travels in register set q % 3 and lands in
@@ -106,14 +129,13 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
     floatx4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    w3_mma4<NS, false>(acc, w1h, w1l, Xs, ad);
+    w4_mma4<NS, false>(acc, w1h, w1l, Xs, ad);
     __syncthreads();
-    w3_mma4<NS, false>(acc, w2h, w2l, Xs + BUF, ad);
+    w4_mma4<NS, false>(acc, w2h, w2l, Xs + BUF, ad);
     if (NRM) {
       // masked statistics of the result over the tile (one pass about a pivot inside the data, see w3_lin2_kernel)
       const float* Mb = Ms + (i & 1) * 64;
-      const float first = __shfl(acc[0][0], ci, 64) + bv;
-      const float piv = Mb[0] > 0.f ? first : bv;
+      const float piv = w3_pivot(acc, Mb, lane, ci, bv);
       float s1 = 0.f, s2 = 0.f, n = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -137,6 +159,173 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
     ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, nullptr, m0, P - p0, bv, false, false);
     __syncthreads();
   }
+}
+
+// Fused MLP  out = (W2 LeakyReLU(W1 norm(X) + b1) + b2) * mask  (model/ppgn.py:58-59), one job (m1 or m2) per workgroup.
+// Stagers: X tiles (NRM: through the source's instance norm, a.aff) and the tile's mask row.  Multipliers hold both matrices'
+// fragments; per barrier interval they finish tile i-1 (second product from the hidden image H[(i-1) & 1], bias, mask, 16-byte
+// stores) and start tile i (first product from X[i & 1], bias, LeakyReLU, split into the hidden image H[i & 1]): one barrier
+// per tile, X and H double-buffered.  Tile i travels in register set i % 3.
+template <int NS, bool NRM>
+__global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem4[];
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int BUF = NIMG * W3_IMG;
+  char* Xs = smem4;                                          // [2][BUF]
+  char* Hs = smem4 + 2 * BUF;                                // [2][BUF]
+  float* Ms = reinterpret_cast<float*>(smem4 + 4 * BUF);     // [4][64] mask rows: tile i is written in step i-1 and read in step i+1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 3, w8 = wave & 7;
+  const int g = lane >> 4, ci = lane & 15, ch = 16 * w8 + ci;
+  const WsWho who = ws_who(a.njobs);
+  const WsJob& J = a.job[who.jid];
+  const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;
+  if (who.rank >= ntiles) return;                            // whole workgroup, before any barrier
+  const int nloc = (ntiles - who.rank + who.per_job - 1) / who.per_job;   // tiles rank + i * per_job
+  const float* maskp = a.maskp;
+
+  if (role == 0) {
+    // ------------------------------------------------------------------------------------------------ stagers
+    const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);
+    const int oc = 4 * (tid & 15);
+    int qi = 0;
+    auto issue = [&](W4Pre& pre) {
+      const int t = who.rank + (qi < nloc ? qi : nloc - 1) * who.per_job;
+      const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
+      const float* Xt = J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);
+      pre.a = *reinterpret_cast<const float4*>(Xt);
+      pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+      pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+      pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+      if (NRM) {
+        const float* T = a.aff + (size_t)b * 256 + 4 * (tid >> 4);
+        pre.sc = *reinterpret_cast<const float4*>(T);
+        pre.sh = *reinterpret_cast<const float4*>(T + 128);
+      }
+      if (maskp) pre.m = maskp[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
+      ++qi;
+    };
+    int li = 0;
+    auto land = [&](const W4Pre& pre) {                      // tile li -> X[li & 1], mask row li & 3
+      const int t = who.rank + (li < nloc ? li : nloc - 1) * who.per_job;
+      const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
+      const bool in = li < nloc && p0 + oc < P;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+      if (NRM) { w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w); }
+      w3_tile_store4<NS>(xa, xb, xc, xd, Xs + (li & 1) * BUF, tid);
+      if (tid < 64) Ms[(li & 3) * 64 + tid] = (maskp && li < nloc && p0 + lane < P) ? pre.m : (maskp ? 0.f : 1.f);
+      ++li;
+    };
+    W4Pre p0s, p1s, p2s;
+    p0s.m = p1s.m = p2s.m = 1.f;
+    issue(p0s); issue(p1s); issue(p2s);
+    land(p0s);
+    __syncthreads();                                         // tile 0 is in X[0]
+    // steps i = 0 .. nloc: tile i's first product runs, tile i+1 lands, tile i+3 is requested
+    for (int q = 0; q <= nloc; q += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (q + u <= nloc) {
+          if (u == 0) { issue(p0s); land(p1s); }
+          else if (u == 1) { issue(p1s); land(p2s); }
+          else { issue(p2s); land(p0s); }
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- multipliers
+  uintx4 w1h[4], w1l[4], w2h[4], w2l[4];
+  w3_load_w<NS, false>(w1h, w1l, J.W1, J.ldw1, ch, g);
+  w3_load_w<NS, false>(w2h, w2l, J.W2, J.ldw2, ch, g);
+  float b1v[4];                                              // first product: the lane's channels 16 w8 + 4 g + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b1v[r] = J.b1 ? J.b1[16 * w8 + 4 * g + r] : 0.f;
+  const float b2v = J.b2 ? J.b2[ch] : 0.f;                   // second product: channel ch
+  const W3Addr ad = w3_addr(ci, g);
+  const unsigned hbase = ci * 256 + (g & 1) * 8, hchunk = (2 * w8 + (g >> 1)) ^ ci;
+  const unsigned r0 = (unsigned)ch * P + 4 * g;
+  const unsigned m0 = 4 * g;
+  __syncthreads();                                           // tile 0 is in X[0]
+  for (int i = 0; i <= nloc; ++i) {
+    if (i >= 1) {                                            // finish tile i-1
+      const int t = who.rank + (i - 1) * who.per_job;
+      const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
+      floatx4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      w4_mma4<NS, false>(acc, w2h, w2l, Hs + ((i - 1) & 1) * BUF, ad);
+      const float* Mb = Ms + ((i - 1) & 3) * 64;
+      float* Yt = J.Y + (size_t)b * J.y_bs + p0;
+      const int lim = P - p0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pj = (int)m0 + 16 * j;
+        if (pj < lim) {
+          float4 v = ws_f4(acc[j]);
+          v.x += b2v; v.y += b2v; v.z += b2v; v.w += b2v;
+          const float4 m = *reinterpret_cast<const float4*>(Mb + pj);
+          v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+          *reinterpret_cast<float4*>(Yt + r0 + 16 * j) = v;
+        }
+      }
+    }
+    if (i < nloc) {                                          // start tile i
+      char* Hb = Hs + (i & 1) * BUF;
+      floatx4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      w4_mma4<NS, true>(acc, w1h, w1l, Xs + (i & 1) * BUF, ad);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned h01, l01 = 0, h23, l23 = 0;
+        w3_split2<NS>(ws_leaky(acc[j][0] + b1v[0]), ws_leaky(acc[j][1] + b1v[1]), h01, l01);
+        w3_split2<NS>(ws_leaky(acc[j][2] + b1v[2]), ws_leaky(acc[j][3] + b1v[3]), h23, l23);
+        const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
+        *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
+        if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NS>
+static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
+  static bool set[2] = {false, false};
+  const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + 4 * 64 * sizeof(float);
+  const bool nrm = a.aff != nullptr;
+  auto kern = nrm ? w4_mlp_kernel<NS, true> : w4_mlp_kernel<NS, false>;
+  if (!set[nrm]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "w4_mlp: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    set[nrm] = true;
+  }
+  const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
+  const long slots = w3_slots(a.njobs, ntiles);              // one workgroup per CU: 32 per XCD, jobs that share X on one XCD
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W4_THREADS), lds, st, a);
+  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
+  return check_launch("w4_mlp");
+}
+
+bool w4_mlp_ok(const WsArgs& a) {
+  if (a.njobs < 1 || a.njobs > WS_MAX_JOBS || a.P % 4 != 0 || (long)WS_H * a.P >= (1L << 31) || (a.maskp && !ws_al16(a.maskp))) return false;
+  for (int i = 0; i < a.njobs; ++i) {
+    const WsJob& j = a.job[i];
+    if (!j.X || !j.W1 || !j.W2 || !j.Y || j.Mid || j.accumulate || !ws_al16(j.X) || !ws_al16(j.Y) || j.x_bs % 4 || j.y_bs % 4) return false;
+  }
+  return true;
+}
+
+int w4_mlp_run(const WsArgs& a, int ns, hipStream_t st) {
+  if (!w4_mlp_ok(a)) return fail(DPPM_E_INVALID, "w4_mlp: unsupported arguments");
+  return ns == 3 ? w4_mlp_launch<3>(a, st) : w4_mlp_launch<1>(a, st);
 }
 
 template <int NS>

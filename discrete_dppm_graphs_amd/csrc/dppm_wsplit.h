@@ -176,6 +176,21 @@ __device__ __forceinline__ void w3_mma4(floatx4 (&acc)[4], const uintx4 (&wh)[4]
   }
 }
 
+// Pivot of the one-pass tile statistics: the channel's value at the tile's FIRST UNMASKED position (mask row Mb[64]).  Lane (g, ci)
+// holds positions 16 j + 4 g + r of channel ci in acc[j][r].  The pivot has to lie inside the data: a masked position holds
+// anything, and a pivot k standard deviations off the mean costs S2 - S1^2 / n about eps k^2 of its digits.
+__device__ __forceinline__ float w3_pivot(const floatx4 (&acc)[4], const float* Mb, int lane, int ci, float bv) {
+  const unsigned long long bal = __ballot(Mb[lane] > 0.f);
+  const int ps = __builtin_amdgcn_readfirstlane(bal ? __builtin_ctzll(bal) : 0);
+  const int js = ps >> 4, gs = (ps >> 2) & 3, rs = ps & 3;
+  float cand = acc[0][0];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cand = (js == j && rs == r) ? acc[j][r] : cand;
+  return __shfl(cand, 16 * gs + ci, 64) + bv;
+}
+
 // Y (+)= epilogue(sum_s W_s X_s + b): one or two 128-channel sources, optional rank-2 side input, LeakyReLU, mask.
 template <int NS, int NSRC, bool TRANS>
 __global__ __launch_bounds__(WS_THREADS, 4) void w3_lin_kernel(const WsArgs a) {
@@ -593,12 +608,10 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
       }
       if (NRM && !(a.dbg & 1)) {
         // statistics of the result over the tile's unmasked positions: the lane holds 16 positions of channel ch, the other 48
-        // sit in the lanes that share ci.  One pass about a pivot that lies inside the data (the channel's value at the tile's first
-        // position, or the bias if that position is masked), so that S2 - S1^2 / n loses no digits to a large mean; three sums,
-        // two shuffle stages.  Selects, not products: a masked position may hold anything.
+        // sit in the lanes that share ci.  One pass about a pivot that lies inside the data (w3_pivot), so that S2 - S1^2 / n loses
+        // no digits to a large mean; three sums, two shuffle stages.  Selects, not products: a masked position may hold anything.
         const float* Mb = Ms + (i & 1) * 64;
-        const float first = __shfl(acc[0][0], ci, 64) + bv;          // lane (g = 0, ci): position 0 of the tile
-        const float piv = Mb[0] > 0.f ? first : bv;
+        const float piv = w3_pivot(acc, Mb, lane, ci, bv);
         float s1 = 0.f, s2 = 0.f, n = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
