@@ -1,0 +1,250 @@
+// Per-channel N x N contraction C[g] = A[g] * B[g] * scale (model/ppgn.py:62-64), split-bf16 arithmetic, 129 <= N <= 256:
+// the role-split, persistent form of dppm_planesplit.h (same LDS images, same MFMA operand order, same results bit for bit).
+//
+// plane3_kernel lets all 16 waves stage a K = 32 panel AND multiply the previous one: one panel (53 KB) in flight per CU, and
+// only between its request and its landing -- at ~2 us of HBM latency under load that duty cycle, not the matrix pipe (19 %
+// busy, rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES) or the LDS (17 %), set its 3.6 TB/s.  Here one 12-wave workgroup per CU walks its
+// planes as ONE stream of panels:
+//   waves 0-3  (stagers)     keep two panels in flight in registers beside the one they are landing (split into bf16 hi / lo
+//                            images, B transposed on the way); they never wait for a multiplier except at the panel barrier
+//                            and run ahead across plane boundaries;
+//   waves 4-11 (multipliers) own the 16 x 16 output tiles in a 4 (row groups) x 2 (column halves) cut -- up to 4 x 7 tiles in
+//                            112 accumulator registers at 3 waves per SIMD (168 registers) -- read fragments from LDS, and at a
+//                            plane's last panel scale and store their tiles with 16-byte stores while the stagers go on.
+// One barrier per panel; LDS: two panel stages (106 KB at N = 200).
+#include "dppm_plane4.h"
+#include "dppm_planesplit.h"
+
+namespace dppm {
+
+constexpr int P4_THREADS = 768;
+constexpr int P4_STAGERS = 256;
+constexpr int P4_CUS = 256;                                   // MI355X: 8 XCDs x 32 CUs
+
+template <int NT>
+struct P4Cfg {
+  static constexpr int ROWS = NT * 16;
+  static constexpr int IMG = ROWS * 64;                       // bytes of one bf16 image of one operand panel
+  static constexpr int NQ = ROWS / 4;                         // float4 columns of a B panel row
+  static constexpr int VA = (ROWS * 8 + P4_STAGERS - 1) / P4_STAGERS;     // float4 per staging thread, A side: (row, 4 k)
+  static constexpr int VB = (8 * NQ + P4_STAGERS - 1) / P4_STAGERS;       // quads per staging thread, B side: (4 k rows, 4 columns)
+};
+
+template <int VA, int VB>
+struct P4Pre { float4 a[VA]; float4 b[VB][4]; };
+
+template <int NT, int NS, int NR, int NC>
+__device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds, int r0, int c0, int lane, int nloc, int np, int dbg) {
+  using Cfg = P4Cfg<NT>;
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int OPB = NIMG * Cfg::IMG, STAGE = 2 * OPB;
+  const int n = p.n, ld = p.ld;
+  const size_t plane = (size_t)n * ld;
+  const int wcols = ld < Cfg::ROWS ? ld : Cfg::ROWS;
+  const int ci = lane & 15, gq = lane >> 4;
+  // p3_off(16 t + ci, gq) = 1024 t + p3_off(ci, gq): one lane offset, tile offsets as immediates
+  const unsigned abase = p3_off(ci, gq) + r0 * 1024, bbase = OPB + p3_off(ci, gq) + c0 * 1024;
+  floatx4 acc[NR][NC];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                            // panel 0 is in stage 0
+  int q = 0;
+  for (int i = 0; i < nloc; ++i) {
+    for (int kp = 0; kp < np; ++kp, ++q) {
+      const char* st = lds + (q & 1) * STAGE;
+      if (!(dbg & 1))
+#pragma unroll
+      for (int ii = 0; ii < NR; ++ii) {
+        const uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase + ii * 1024);
+        uintx4 al = ah;
+        if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase + ii * 1024);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          const uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase + j * 1024);
+          if (NS > 1) {
+            const uintx4 bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase + j * 1024);
+            acc[ii][j] = w3_mfma(bl, ah, acc[ii][j]);
+            acc[ii][j] = w3_mfma(bh, al, acc[ii][j]);
+          }
+          acc[ii][j] = w3_mfma(bh, ah, acc[ii][j]);
+        }
+      }
+      if (kp == np - 1 && !(dbg & 8)) {                                     // the plane is complete: scale, store, start over
+        const long g = (long)blockIdx.x + (long)i * gridDim.x;
+        const float scale = p.scale ? p.scale[g / p.div] : 1.f;
+        const float* mask = p.mask ? p.mask + (size_t)(g / p.div) * plane : nullptr;
+        float* C = p.C + g * plane;
+#pragma unroll
+        for (int ii = 0; ii < NR; ++ii)
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            p3_store_tile(acc[ii][j], C, mask, scale, (r0 + ii) * 16, (c0 + j) * 16, n, n, wcols, ld, lane);
+            acc[ii][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NT, int NS>
+__global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, int batch, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char lds4[];
+  using Cfg = P4Cfg<NT>;
+  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int OPB = NIMG * Cfg::IMG, STAGE = 2 * OPB;
+  constexpr int VA = Cfg::VA, VB = Cfg::VB, NQ = Cfg::NQ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = p.n, ld = p.ld;
+  const int np = (n + P3_BK - 1) / P3_BK;
+  if ((int)blockIdx.x >= batch) return;                       // whole workgroup, before any barrier
+  const int nloc = (batch - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // planes blockIdx.x + i * gridDim.x
+  const int nq = nloc * np;                                   // panels of this workgroup, one stream
+
+  if (wave >= P4_STAGERS / 64) {
+    // ---------------------------------------------------------------------------------------------- multipliers
+    constexpr int BASE = NT / 4, REM = NT % 4;                // row group a: BASE + (a < REM) tiles
+    constexpr int CH0 = (NT + 1) / 2, CH1 = NT / 2;           // column halves
+    const int m = wave - P4_STAGERS / 64, a = m >> 1, b = m & 1;
+    const int r0 = a * BASE + (a < REM ? a : REM), c0 = b ? CH0 : 0;
+    const bool rbig = a < REM;
+    if (CH0 == CH1) {
+      if (REM != 0 && rbig) p4_multiply<NT, NS, BASE + 1, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
+      else p4_multiply<NT, NS, BASE, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
+    } else {
+      if (REM != 0 && rbig && b == 0) p4_multiply<NT, NS, BASE + 1, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
+      else if (REM != 0 && rbig) p4_multiply<NT, NS, BASE + 1, CH1>(p, lds4, r0, c0, lane, nloc, np, dbg);
+      else if (b == 0) p4_multiply<NT, NS, BASE, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
+      else p4_multiply<NT, NS, BASE, CH1>(p, lds4, r0, c0, lane, nloc, np, dbg);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- stagers
+  const size_t plane = (size_t)n * ld;
+  const int wcols = ld < Cfg::ROWS ? ld : Cfg::ROWS;
+  const int akq = tid & 7, arow = tid >> 3;                   // A side: k = 4 akq .., rows arow + 32 v
+  int bkq[VB], bnq[VB];                                       // B side: quad e = tid + 256 v -> (k = 4 bkq .., columns 4 bnq ..)
+#pragma unroll
+  for (int v = 0; v < VB; ++v) { const int e = tid + P4_STAGERS * v; bkq[v] = e / NQ; bnq[v] = e - bkq[v] * NQ; }
+  int ii = 0, ikp = 0;                                        // issue cursor (plane, panel); clamped at the stream's end
+  auto issue = [&](P4Pre<VA, VB>& pre) {
+    if (dbg & 4) return;
+    const long g = (long)blockIdx.x + (long)ii * gridDim.x;
+    const int k0 = ikp * P3_BK;
+    const float* A = p.A + g * plane;
+    const float* B = p.B + g * plane;
+    const int ka = k0 + 4 * akq;
+#pragma unroll
+    for (int v = 0; v < VA; ++v) {
+      const int row = arow + 32 * v;
+      pre.a[v] = *reinterpret_cast<const float4*>(A + (size_t)(row < n ? row : 0) * ld + (ka < ld ? ka : 0));
+    }
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      const int k = k0 + 4 * bkq[v];
+      const float* b0 = B + ((bkq[v] < 8 && 4 * bnq[v] < wcols) ? 4 * bnq[v] : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre.b[v][r] = *reinterpret_cast<const float4*>(b0 + (size_t)(k + r < n ? k + r : 0) * ld);
+    }
+    if (ii < nloc - 1 || ikp < np - 1) { if (++ikp == np) { ikp = 0; ++ii; } }
+  };
+  int lkp = 0;                                                // landing cursor (panel index inside its plane)
+  auto land = [&](const P4Pre<VA, VB>& pre, char* stage) {
+    if (dbg & 2) return;
+    const int k0 = lkp * P3_BK;
+    {
+      const int k = k0 + 4 * akq;
+      const bool k0ok = k + 0 < n, k1ok = k + 1 < n, k2ok = k + 2 < n, k3ok = k + 3 < n;
+      const unsigned cb = akq >> 1, hb = (akq & 1) * 8;
+#pragma unroll
+      for (int v = 0; v < VA; ++v) {
+        const int row = arow + 32 * v;
+        if (row < Cfg::ROWS) {
+          const bool r = row < n;
+          const float4 x = pre.a[v];
+          p3_put<NS>(stage, p3_off(row, cb) + hb, Cfg::IMG, r && k0ok ? x.x : 0.f, r && k1ok ? x.y : 0.f, r && k2ok ? x.z : 0.f, r && k3ok ? x.w : 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      if (bkq[v] < 8) {
+        const int k = k0 + 4 * bkq[v];
+        const bool k0ok = k + 0 < n, k1ok = k + 1 < n, k2ok = k + 2 < n, k3ok = k + 3 < n;
+        const unsigned cb = bkq[v] >> 1, hb = (bkq[v] & 1) * 8;
+        char* img = stage + OPB;
+        const int row = 4 * bnq[v];
+        const float4 x0 = pre.b[v][0], x1 = pre.b[v][1], x2 = pre.b[v][2], x3 = pre.b[v][3];
+        const bool c0 = row + 0 < n, c1 = row + 1 < n, c2 = row + 2 < n, c3 = row + 3 < n;
+        p3_put<NS>(img, p3_off(row + 0, cb) + hb, Cfg::IMG, c0 && k0ok ? x0.x : 0.f, c0 && k1ok ? x1.x : 0.f, c0 && k2ok ? x2.x : 0.f, c0 && k3ok ? x3.x : 0.f);
+        p3_put<NS>(img, p3_off(row + 1, cb) + hb, Cfg::IMG, c1 && k0ok ? x0.y : 0.f, c1 && k1ok ? x1.y : 0.f, c1 && k2ok ? x2.y : 0.f, c1 && k3ok ? x3.y : 0.f);
+        p3_put<NS>(img, p3_off(row + 2, cb) + hb, Cfg::IMG, c2 && k0ok ? x0.z : 0.f, c2 && k1ok ? x1.z : 0.f, c2 && k2ok ? x2.z : 0.f, c2 && k3ok ? x3.z : 0.f);
+        p3_put<NS>(img, p3_off(row + 3, cb) + hb, Cfg::IMG, c3 && k0ok ? x0.w : 0.f, c3 && k1ok ? x1.w : 0.f, c3 && k2ok ? x2.w : 0.f, c3 && k3ok ? x3.w : 0.f);
+      }
+    }
+    if (++lkp == np) lkp = 0;
+  };
+
+  P4Pre<VA, VB> s0, s1;
+  issue(s0); issue(s1);                                       // panels 0, 1
+  land(s0, lds4);
+  issue(s0);                                                  // panel 2
+  __syncthreads();                                            // panel 0 is in stage 0
+  // interval q: the multipliers work on panel q; panel q+1 lands in the other stage from set (q+1) & 1, which then takes panel q+3
+  for (int q = 0; q < nq; q += 2) {
+    if (q + 1 < nq) { land(s1, lds4 + STAGE); issue(s1); }
+    __syncthreads();
+    if (q + 1 < nq) {
+      if (q + 2 < nq) { land(s0, lds4); issue(s0); }
+      __syncthreads();
+    }
+  }
+}
+
+static int p4_dbg() { const char* e = getenv("DPPM_DBG_P4"); return e ? atoi(e) : 0; }   // timing experiments only: results are wrong
+
+template <int NT, int NS>
+static int plane4_launch_nt(const PlaneArgs& a, int batch, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t lds = (size_t)2 * 2 * (NS > 1 ? 2 : 1) * P4Cfg<NT>::IMG;   // stages x operands x images
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane4_kernel<NT, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(DPPM_E_LAUNCH, "plane4: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    attr_set = true;
+  }
+  const int grid = batch < P4_CUS ? batch : P4_CUS;           // one workgroup per CU, planes dealt round-robin
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(plane4_kernel<NT, NS>), dim3(grid), dim3(P4_THREADS), lds, st, a, batch, p4_dbg());
+  return check_launch("plane4");
+}
+
+bool plane4_ok(const PlaneArgs& a, int batch) {
+  const int nt = cdiv(a.n, 16);
+  return nt >= 9 && nt <= 14 && a.ld % 4 == 0 && a.ld >= a.n && batch > 0 && (long)batch * a.n * a.ld < (1L << 40);
+}
+
+template <int NS>
+static int plane4_dispatch(const PlaneArgs& a, int batch, hipStream_t st) {
+  switch (cdiv(a.n, 16)) {
+    case 9: return plane4_launch_nt<9, NS>(a, batch, st);
+    case 10: return plane4_launch_nt<10, NS>(a, batch, st);
+    case 11: return plane4_launch_nt<11, NS>(a, batch, st);
+    case 12: return plane4_launch_nt<12, NS>(a, batch, st);
+    case 13: return plane4_launch_nt<13, NS>(a, batch, st);
+    case 14: return plane4_launch_nt<14, NS>(a, batch, st);
+    default: return fail(DPPM_E_UNSUPPORTED, "plane4: n=%d outside 129..224", a.n);
+  }
+}
+
+int plane4_run(const PlaneArgs& a, int batch, int ns, hipStream_t st) {
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  const int rc = ns > 1 ? plane4_dispatch<3>(a, batch, st) : plane4_dispatch<1>(a, batch, st);
+  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
+  return rc;
+}
+
+}  // namespace dppm

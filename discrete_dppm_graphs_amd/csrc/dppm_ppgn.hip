@@ -14,6 +14,7 @@
 #include "dppm_wsplit.h"
 #include "dppm_head.h"
 #include "dppm_w4.h"
+#include "dppm_plane4.h"
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
 #include "dppm_planesplit.h"
@@ -882,7 +883,8 @@ int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batc
              const float* scale, const float* mask, int div, int prec = DPPM_PREC_F32) {
   static const bool strip_off = getenv("DPPM_DISABLE_STRIPMM") != nullptr;   // A/B switch for measurements
   if (prec != DPPM_PREC_F32 && !ta && !tb && plane3_supported(n) && aligned16(A) && aligned16(Bm) && aligned16(C)) {
-    PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // forward form on the bf16 pipe (dppm_planesplit.h)
+    PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // forward form on the bf16 pipe (dppm_plane4.hip, dppm_planesplit.h)
+    if (getenv("DPPM_DISABLE_PLANE4") == nullptr && plane4_ok(pa, batch)) return plane4_run(pa, batch, prec == DPPM_PREC_BF16X3 ? 3 : 1, st);
     return prec == DPPM_PREC_BF16X3 ? plane3_launch<3>(pa, batch, st) : plane3_launch<1>(pa, batch, st);
   }
   if (plane_mm_supported(n) && !strip_off && aligned16(A) && aligned16(Bm) && aligned16(C)) {

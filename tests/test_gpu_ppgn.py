@@ -302,6 +302,29 @@ def test_plane_matmul_reduced_precision(ops, n, precision, tol):
     assert np.all(out[:, :, n:] == 0)
 
 
+@pytest.mark.parametrize("n,batch", [(200, 600), (203, 300), (150, 257), (224, 70)])
+def test_plane_matmul_persistent_stream(ops, n, batch, monkeypatch):
+    """The role-split contraction (dppm_plane4.hip) walks several planes per workgroup as one stream of K panels (batch > 256
+    workgroups, uneven shares): bit-identical to the one-plane-per-workgroup kernel of dppm_planesplit.h, and right in float64."""
+    rng = np.random.default_rng(n + batch)
+    ld = (n + 3) // 4 * 4
+    A = np.zeros((batch, n, ld), np.float32)
+    Bm = np.zeros((batch, n, ld), np.float32)
+    A[:, :, :n] = rng.normal(size=(batch, n, n))
+    Bm[:, :, :n] = rng.normal(size=(batch, n, n))
+    scale = rng.uniform(0.5, 2, size=batch).astype(np.float32)
+    for precision, tol in (("bf16x3", 3e-5), ("bf16", 2e-2)):
+        monkeypatch.delenv("DPPM_DISABLE_PLANE4", raising=False)
+        out = ops.plane_matmul(dev(A), dev(Bm), n, scale=dev(scale), scale_div=1, precision=precision).cpu().numpy()
+        monkeypatch.setenv("DPPM_DISABLE_PLANE4", "1")
+        old = ops.plane_matmul(dev(A), dev(Bm), n, scale=dev(scale), scale_div=1, precision=precision).cpu().numpy()
+        assert np.array_equal(out, old)
+        sel = rng.choice(batch, size=8, replace=False)
+        ref = (A[sel, :, :n].astype(np.float64) @ Bm[sel, :, :n].astype(np.float64)) * scale[sel, None, None]
+        close(out[sel, :, :n], ref, tol=tol)
+        assert np.all(out[:, :, n:] == 0)
+
+
 @pytest.mark.parametrize("M,K,P,B", [(8, 8, 48, 2), (34, 16, 1188, 3), (64, 64, 64, 2), (40, 64, 400, 1), (128, 128, 3600, 2),
                                      (194, 64, 64, 2), (66, 32, 400, 2), (32, 2, 400, 2), (130, 20, 132, 1),
                                      # 32 x 32: the dedicated small-network kernels (lin32t_kernel, wgrad32_kernel) and their generic fallback
