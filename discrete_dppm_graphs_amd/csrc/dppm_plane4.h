@@ -1,4 +1,4 @@
-// Role-split persistent form of the split-bf16 per-channel contraction for 129 <= N <= 224 (dppm_plane4.hip).
+// Role-split persistent form of the split-bf16 per-channel contraction for 129 <= N <= 512 (dppm_plane4.hip).
 #pragma once
 #include "dppm_planemm.h"
 

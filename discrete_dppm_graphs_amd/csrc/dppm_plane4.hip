@@ -1,4 +1,4 @@
-// Per-channel N x N contraction C[g] = A[g] * B[g] * scale (model/ppgn.py:62-64), split-bf16 arithmetic, 129 <= N <= 256:
+// Per-channel N x N contraction C[g] = A[g] * B[g] * scale (model/ppgn.py:62-64), split-bf16 arithmetic, 129 <= N <= 512:
 // the role-split, persistent form of dppm_planesplit.h (same LDS images, same MFMA operand order, same results bit for bit).
 //
 // plane3_kernel lets all 16 waves stage a K = 32 panel AND multiply the previous one: one panel (53 KB) in flight per CU, and
@@ -30,17 +30,36 @@ struct P4Cfg {
   static constexpr int VB = (8 * NQ + P4_STAGERS - 1) / P4_STAGERS;       // quads per staging thread, B side: (4 k rows, 4 columns)
 };
 
+// The workgroup's share: planes group + i * ngroups, output block (mlo, nlo) of each.  NBLK = 2 (planes cut into 2 x 2 blocks of
+// 16 NT rows, K = n): the four workgroups blockIdx.x = x + 8 (4 s + member), member = 0..3, sit on one XCD (workgroups go to XCDs
+// round-robin) and walk the same planes in step, so each half of A and of B is fetched from HBM once and found in that XCD's L2
+// by its second reader.
+struct P4Work { int group, ngroups, mlo, nlo; };
+template <int NBLK, int ROWS>
+__device__ __forceinline__ P4Work p4_work() {
+  P4Work w;
+  if (NBLK == 1) { w.group = blockIdx.x; w.ngroups = gridDim.x; w.mlo = 0; w.nlo = 0; }
+  else {
+    const int x = blockIdx.x, member = (x >> 3) & 3;
+    w.group = (x & 7) + 8 * (x >> 5); w.ngroups = gridDim.x >> 2;
+    w.mlo = (member >> 1) * ROWS; w.nlo = (member & 1) * ROWS;
+  }
+  return w;
+}
+
 template <int VA, int VB>
 struct P4Pre { float4 a[VA]; float4 b[VB][4]; };
 
 template <int NT, int NS, int NR, int NC>
-__device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds, int r0, int c0, int lane, int nloc, int np, int dbg) {
+__device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds, int r0, int c0, int lane, int nloc, int np, int dbg, const P4Work& wk) {
   using Cfg = P4Cfg<NT>;
   constexpr int NIMG = NS > 1 ? 2 : 1;
   constexpr int OPB = NIMG * Cfg::IMG, STAGE = 2 * OPB;
   const int n = p.n, ld = p.ld;
   const size_t plane = (size_t)n * ld;
-  const int wcols = ld < Cfg::ROWS ? ld : Cfg::ROWS;
+  const int nrows = n - wk.mlo < Cfg::ROWS ? n - wk.mlo : Cfg::ROWS, ncols = n - wk.nlo < Cfg::ROWS ? n - wk.nlo : Cfg::ROWS;
+  const int wcols = ld - wk.nlo < Cfg::ROWS ? ld - wk.nlo : Cfg::ROWS;   // ld % 4 == 0, nlo % 16 == 0: whole float4s
+  const size_t boff = (size_t)wk.mlo * ld + wk.nlo;
   const int ci = lane & 15, gq = lane >> 4;
   // p3_off(16 t + ci, gq) = 1024 t + p3_off(ci, gq): one lane offset, tile offsets as immediates
   const unsigned abase = p3_off(ci, gq) + r0 * 1024, bbase = OPB + p3_off(ci, gq) + c0 * 1024;
@@ -49,47 +68,88 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
   for (int i = 0; i < NR; ++i)
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // A finished plane leaves in one burst after its last panel (measured: spreading it over two intervals -- half the row tiles
+  // now, half before the next plane's first MFMAs -- was 5 % slower; streaming "nt" stores 40 % slower: the L2 merges the 64-byte
+  // row pieces of neighbouring tiles).
+  auto store_plane = [&](int i) {
+    const long g = (long)wk.group + (long)i * wk.ngroups;
+    const float scale = p.scale ? p.scale[g / p.div] : 1.f;
+    const float* mask = p.mask ? p.mask + (size_t)(g / p.div) * plane + boff : nullptr;
+    float* C = p.C + g * plane + boff;
+#pragma unroll
+    for (int ii = 0; ii < NR; ++ii)
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        p3_store_tile(acc[ii][j], C, mask, scale, (r0 + ii) * 16, (c0 + j) * 16, nrows, ncols, wcols, ld, lane);
+        acc[ii][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
   __syncthreads();                                            // panel 0 is in stage 0
   int q = 0;
   for (int i = 0; i < nloc; ++i) {
     for (int kp = 0; kp < np; ++kp, ++q) {
       const char* st = lds + (q & 1) * STAGE;
-      if (!(dbg & 1))
+      if (!(dbg & 1)) {
+        // fragments one (row tile, column tile) step ahead of the MFMAs that use them; the order is pinned (sched_group_barrier) so
+        // that the scheduler does not hoist a panel's worth of reads over the accumulators' registers
+        constexpr bool AHEAD = NR * NC <= 28;                 // 32 tiles: no registers left for the second fragment set
+        if (AHEAD) {
+        uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase), al = ah;
+        if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase);
+        uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase), bl = bh;
+        if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase);
 #pragma unroll
-      for (int ii = 0; ii < NR; ++ii) {
-        const uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase + ii * 1024);
-        uintx4 al = ah;
-        if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase + ii * 1024);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-          const uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase + j * 1024);
-          if (NS > 1) {
-            const uintx4 bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase + j * 1024);
-            acc[ii][j] = w3_mfma(bl, ah, acc[ii][j]);
-            acc[ii][j] = w3_mfma(bh, al, acc[ii][j]);
+        for (int t = 0; t < NR * NC; ++t) {
+          const int ii = t / NC, j = t % NC;
+          const uintx4 cah = ah, cal = al, cbh = bh, cbl = bl;
+          if (t + 1 < NR * NC) {
+            const int in = (t + 1) / NC, jn = (t + 1) % NC;
+            bh = *reinterpret_cast<const uintx4*>(st + bbase + jn * 1024);
+            if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase + jn * 1024);
+            if (jn == 0) {
+              ah = *reinterpret_cast<const uintx4*>(st + abase + in * 1024);
+              if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase + in * 1024);
+            }
+            if (jn == 0) __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 4 : 2, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
           }
-          acc[ii][j] = w3_mfma(bh, ah, acc[ii][j]);
+          if (NS > 1) {
+            acc[ii][j] = w3_mfma(cbl, cah, acc[ii][j]);
+            acc[ii][j] = w3_mfma(cbh, cal, acc[ii][j]);
+          }
+          acc[ii][j] = w3_mfma(cbh, cah, acc[ii][j]);
+          __builtin_amdgcn_sched_group_barrier(0x008, NS > 1 ? 3 : 1, 0);
         }
-      }
-      if (kp == np - 1 && !(dbg & 8)) {                                     // the plane is complete: scale, store, start over
-        const long g = (long)blockIdx.x + (long)i * gridDim.x;
-        const float scale = p.scale ? p.scale[g / p.div] : 1.f;
-        const float* mask = p.mask ? p.mask + (size_t)(g / p.div) * plane : nullptr;
-        float* C = p.C + g * plane;
+        } else {
 #pragma unroll
-        for (int ii = 0; ii < NR; ++ii)
+        for (int ii = 0; ii < NR; ++ii) {
+          const uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase + ii * 1024);
+          uintx4 al = ah;
+          if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase + ii * 1024);
+          __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
 #pragma unroll
           for (int j = 0; j < NC; ++j) {
-            p3_store_tile(acc[ii][j], C, mask, scale, (r0 + ii) * 16, (c0 + j) * 16, n, n, wcols, ld, lane);
-            acc[ii][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            const uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase + j * 1024);
+            uintx4 bl = bh;
+            if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase + j * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
+            if (NS > 1) {
+              acc[ii][j] = w3_mfma(bl, ah, acc[ii][j]);
+              acc[ii][j] = w3_mfma(bh, al, acc[ii][j]);
+            }
+            acc[ii][j] = w3_mfma(bh, ah, acc[ii][j]);
+            __builtin_amdgcn_sched_group_barrier(0x008, NS > 1 ? 3 : 1, 0);
           }
+        }
+        }
       }
+      if (kp == np - 1 && !(dbg & 8)) store_plane(i);
       __syncthreads();
     }
   }
 }
 
-template <int NT, int NS>
+template <int NT, int NS, int NBLK>
 __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, int batch, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char lds4[];
   using Cfg = P4Cfg<NT>;
@@ -100,8 +160,9 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = p.n, ld = p.ld;
   const int np = (n + P3_BK - 1) / P3_BK;
-  if ((int)blockIdx.x >= batch) return;                       // whole workgroup, before any barrier
-  const int nloc = (batch - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // planes blockIdx.x + i * gridDim.x
+  const P4Work wk = p4_work<NBLK, Cfg::ROWS>();
+  if (wk.group >= batch || wk.mlo >= n || wk.nlo >= n) return;   // whole workgroup, before any barrier
+  const int nloc = (batch - wk.group + wk.ngroups - 1) / wk.ngroups;   // planes group + i * ngroups
   const int nq = nloc * np;                                   // panels of this workgroup, one stream
 
   if (wave >= P4_STAGERS / 64) {
@@ -112,20 +173,21 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
     const int r0 = a * BASE + (a < REM ? a : REM), c0 = b ? CH0 : 0;
     const bool rbig = a < REM;
     if (CH0 == CH1) {
-      if (REM != 0 && rbig) p4_multiply<NT, NS, BASE + 1, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
-      else p4_multiply<NT, NS, BASE, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
+      if (REM != 0 && rbig) p4_multiply<NT, NS, BASE + 1, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg, wk);
+      else p4_multiply<NT, NS, BASE, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg, wk);
     } else {
-      if (REM != 0 && rbig && b == 0) p4_multiply<NT, NS, BASE + 1, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
-      else if (REM != 0 && rbig) p4_multiply<NT, NS, BASE + 1, CH1>(p, lds4, r0, c0, lane, nloc, np, dbg);
-      else if (b == 0) p4_multiply<NT, NS, BASE, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg);
-      else p4_multiply<NT, NS, BASE, CH1>(p, lds4, r0, c0, lane, nloc, np, dbg);
+      if (REM != 0 && rbig && b == 0) p4_multiply<NT, NS, BASE + 1, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg, wk);
+      else if (REM != 0 && rbig) p4_multiply<NT, NS, BASE + 1, CH1>(p, lds4, r0, c0, lane, nloc, np, dbg, wk);
+      else if (b == 0) p4_multiply<NT, NS, BASE, CH0>(p, lds4, r0, c0, lane, nloc, np, dbg, wk);
+      else p4_multiply<NT, NS, BASE, CH1>(p, lds4, r0, c0, lane, nloc, np, dbg, wk);
     }
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- stagers
   const size_t plane = (size_t)n * ld;
-  const int wcols = ld < Cfg::ROWS ? ld : Cfg::ROWS;
+  const int nrows = n - wk.mlo < Cfg::ROWS ? n - wk.mlo : Cfg::ROWS, ncols = n - wk.nlo < Cfg::ROWS ? n - wk.nlo : Cfg::ROWS;
+  const int wcols = ld - wk.nlo < Cfg::ROWS ? ld - wk.nlo : Cfg::ROWS;
   const int akq = tid & 7, arow = tid >> 3;                   // A side: k = 4 akq .., rows arow + 32 v
   int bkq[VB], bnq[VB];                                       // B side: quad e = tid + 256 v -> (k = 4 bkq .., columns 4 bnq ..)
 #pragma unroll
@@ -133,15 +195,15 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
   int ii = 0, ikp = 0;                                        // issue cursor (plane, panel); clamped at the stream's end
   auto issue = [&](P4Pre<VA, VB>& pre) {
     if (dbg & 4) return;
-    const long g = (long)blockIdx.x + (long)ii * gridDim.x;
+    const long g = (long)wk.group + (long)ii * wk.ngroups;
     const int k0 = ikp * P3_BK;
-    const float* A = p.A + g * plane;
-    const float* B = p.B + g * plane;
+    const float* A = p.A + g * plane + (size_t)wk.mlo * ld;
+    const float* B = p.B + g * plane + wk.nlo;
     const int ka = k0 + 4 * akq;
 #pragma unroll
     for (int v = 0; v < VA; ++v) {
       const int row = arow + 32 * v;
-      pre.a[v] = *reinterpret_cast<const float4*>(A + (size_t)(row < n ? row : 0) * ld + (ka < ld ? ka : 0));
+      pre.a[v] = *reinterpret_cast<const float4*>(A + (size_t)(row < nrows ? row : 0) * ld + (ka < ld ? ka : 0));
     }
 #pragma unroll
     for (int v = 0; v < VB; ++v) {
@@ -164,7 +226,7 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
       for (int v = 0; v < VA; ++v) {
         const int row = arow + 32 * v;
         if (row < Cfg::ROWS) {
-          const bool r = row < n;
+          const bool r = row < nrows;
           const float4 x = pre.a[v];
           p3_put<NS>(stage, p3_off(row, cb) + hb, Cfg::IMG, r && k0ok ? x.x : 0.f, r && k1ok ? x.y : 0.f, r && k2ok ? x.z : 0.f, r && k3ok ? x.w : 0.f);
         }
@@ -179,7 +241,7 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
         char* img = stage + OPB;
         const int row = 4 * bnq[v];
         const float4 x0 = pre.b[v][0], x1 = pre.b[v][1], x2 = pre.b[v][2], x3 = pre.b[v][3];
-        const bool c0 = row + 0 < n, c1 = row + 1 < n, c2 = row + 2 < n, c3 = row + 3 < n;
+        const bool c0 = row + 0 < ncols, c1 = row + 1 < ncols, c2 = row + 2 < ncols, c3 = row + 3 < ncols;
         p3_put<NS>(img, p3_off(row + 0, cb) + hb, Cfg::IMG, c0 && k0ok ? x0.x : 0.f, c0 && k1ok ? x1.x : 0.f, c0 && k2ok ? x2.x : 0.f, c0 && k3ok ? x3.x : 0.f);
         p3_put<NS>(img, p3_off(row + 1, cb) + hb, Cfg::IMG, c1 && k0ok ? x0.y : 0.f, c1 && k1ok ? x1.y : 0.f, c1 && k2ok ? x2.y : 0.f, c1 && k3ok ? x3.y : 0.f);
         p3_put<NS>(img, p3_off(row + 2, cb) + hb, Cfg::IMG, c2 && k0ok ? x0.z : 0.f, c2 && k1ok ? x1.z : 0.f, c2 && k2ok ? x2.z : 0.f, c2 && k3ok ? x3.z : 0.f);
@@ -207,36 +269,52 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
 
 static int p4_dbg() { const char* e = getenv("DPPM_DBG_P4"); return e ? atoi(e) : 0; }   // timing experiments only: results are wrong
 
-template <int NT, int NS>
+template <int NT, int NS, int NBLK>
 static int plane4_launch_nt(const PlaneArgs& a, int batch, hipStream_t st) {
   static bool attr_set = false;
   const size_t lds = (size_t)2 * 2 * (NS > 1 ? 2 : 1) * P4Cfg<NT>::IMG;   // stages x operands x images
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane4_kernel<NT, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane4_kernel<NT, NS, NBLK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "plane4: cannot raise the dynamic LDS limit to %zu bytes", lds);
     attr_set = true;
   }
-  const int grid = batch < P4_CUS ? batch : P4_CUS;           // one workgroup per CU, planes dealt round-robin
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(plane4_kernel<NT, NS>), dim3(grid), dim3(P4_THREADS), lds, st, a, batch, p4_dbg());
+  // one workgroup per CU; NBLK = 1: planes dealt round-robin; NBLK = 2: groups of four workgroups (see P4Work), all 256 launched
+  const int grid = NBLK == 1 ? (batch < P4_CUS ? batch : P4_CUS) : P4_CUS;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(plane4_kernel<NT, NS, NBLK>), dim3(grid), dim3(P4_THREADS), lds, st, a, batch, p4_dbg());
   return check_launch("plane4");
 }
 
+// 129 <= n <= 224: one block per plane; 225 <= n <= 512: 2 x 2 blocks (enough planes to fill the 64 groups)
 bool plane4_ok(const PlaneArgs& a, int batch) {
+  if (a.ld % 4 != 0 || a.ld < a.n || batch <= 0 || (long)batch * a.n * a.ld >= (1L << 40)) return false;
   const int nt = cdiv(a.n, 16);
-  return nt >= 9 && nt <= 14 && a.ld % 4 == 0 && a.ld >= a.n && batch > 0 && (long)batch * a.n * a.ld < (1L << 40);
+  return (nt >= 9 && nt <= 14) || (nt >= 15 && nt <= 32 && batch >= P4_CUS / 8);
 }
 
 template <int NS>
 static int plane4_dispatch(const PlaneArgs& a, int batch, hipStream_t st) {
-  switch (cdiv(a.n, 16)) {
-    case 9: return plane4_launch_nt<9, NS>(a, batch, st);
-    case 10: return plane4_launch_nt<10, NS>(a, batch, st);
-    case 11: return plane4_launch_nt<11, NS>(a, batch, st);
-    case 12: return plane4_launch_nt<12, NS>(a, batch, st);
-    case 13: return plane4_launch_nt<13, NS>(a, batch, st);
-    case 14: return plane4_launch_nt<14, NS>(a, batch, st);
-    default: return fail(DPPM_E_UNSUPPORTED, "plane4: n=%d outside 129..224", a.n);
+  const int nt = cdiv(a.n, 16);
+  if (nt <= 14) switch (nt) {
+    case 9: return plane4_launch_nt<9, NS, 1>(a, batch, st);
+    case 10: return plane4_launch_nt<10, NS, 1>(a, batch, st);
+    case 11: return plane4_launch_nt<11, NS, 1>(a, batch, st);
+    case 12: return plane4_launch_nt<12, NS, 1>(a, batch, st);
+    case 13: return plane4_launch_nt<13, NS, 1>(a, batch, st);
+    case 14: return plane4_launch_nt<14, NS, 1>(a, batch, st);
+    default: break;
+  } else switch (cdiv(nt, 2)) {
+    case 8: return plane4_launch_nt<8, NS, 2>(a, batch, st);
+    case 9: return plane4_launch_nt<9, NS, 2>(a, batch, st);
+    case 10: return plane4_launch_nt<10, NS, 2>(a, batch, st);
+    case 11: return plane4_launch_nt<11, NS, 2>(a, batch, st);
+    case 12: return plane4_launch_nt<12, NS, 2>(a, batch, st);
+    case 13: return plane4_launch_nt<13, NS, 2>(a, batch, st);
+    case 14: return plane4_launch_nt<14, NS, 2>(a, batch, st);
+    case 15: return plane4_launch_nt<15, NS, 2>(a, batch, st);
+    case 16: return plane4_launch_nt<16, NS, 2>(a, batch, st);
+    default: break;
   }
+  return fail(DPPM_E_UNSUPPORTED, "plane4: n=%d outside 129..512", a.n);
 }
 
 int plane4_run(const PlaneArgs& a, int batch, int ns, hipStream_t st) {

@@ -302,10 +302,11 @@ def test_plane_matmul_reduced_precision(ops, n, precision, tol):
     assert np.all(out[:, :, n:] == 0)
 
 
-@pytest.mark.parametrize("n,batch", [(200, 600), (203, 300), (150, 257), (224, 70)])
+@pytest.mark.parametrize("n,batch", [(200, 600), (203, 300), (150, 257), (224, 70), (225, 64), (256, 100), (300, 129), (450, 65), (512, 70)])
 def test_plane_matmul_persistent_stream(ops, n, batch, monkeypatch):
     """The role-split contraction (dppm_plane4.hip) walks several planes per workgroup as one stream of K panels (batch > 256
-    workgroups, uneven shares): bit-identical to the one-plane-per-workgroup kernel of dppm_planesplit.h, and right in float64."""
+    workgroups, uneven shares; N > 224: 2 x 2 output blocks per plane, four workgroups in step): bit-identical to the
+    one-block-per-workgroup kernel of dppm_planesplit.h, and right in float64."""
     rng = np.random.default_rng(n + batch)
     ld = (n + 3) // 4 * 4
     A = np.zeros((batch, n, ld), np.float32)
