@@ -784,9 +784,14 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
       j.X = x; j.x_bs = x_bs; j.W1 = w0[k]; j.W2 = w1[k]; j.ldw1 = H; j.ldw2 = H; j.b1 = b0[k]; j.b2 = b1[k];
       j.Mid = save_hid ? hid[k] : nullptr; j.mid_bs = hs; j.Y = out[k]; j.y_bs = hs;
     }
-    // split inference modes: staging waves / multiplying waves (dppm_w4.hip); DPPM_DISABLE_W4=1 keeps the forms of dppm_wsplit.h
-    if (!save_hid && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && getenv("DPPM_W4MLP") != nullptr && w4_mlp_ok(wa))
-      return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
+    // split inference modes.  The two organisations run at the same speed at N = 200 (0.58 ms: both are bound by what one CU moves,
+    // X being fetched by the m1 and the m2 workgroup); the form of dppm_wsplit.h is the default, the role-split one (dppm_w4.hip) takes
+    // over where the fused instance norm needs it (per-graph tables that do not fit the former's LDS) or with DPPM_W4MLP=1.
+    if (!save_hid && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_mlp_ok(wa)) {
+      const int tpp = (c.P + WS_TP - 1) / WS_TP;
+      const bool tables_fit = w3_contig_ok((long)c.B * tpp, tpp, (int)(8 * w3_slots(2, (long)c.B * tpp)));
+      if ((aff && !tables_fit) || getenv("DPPM_W4MLP") != nullptr) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
+    }
     if (!save_hid && prec == DPPM_PREC_BF16X3) return w3_mlp_forward<3>(wa, c.st);
     if (!save_hid && prec == DPPM_PREC_BF16) return w3_mlp_forward<1>(wa, c.st);
     return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
@@ -1031,7 +1036,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   const int tpp = (P + WS_TP - 1) / WS_TP;
   const bool fuse_norm = use_wstat(H) && !training && prec != DPPM_PREC_F32 && !pr->layer_cond && getenv("DPPM_DISABLE_NORMFUSE") == nullptr &&
                          getenv("DPPM_DISABLE_HEAD3") == nullptr &&
-                         ((getenv("DPPM_DISABLE_W4") == nullptr && getenv("DPPM_W4MLP") != nullptr) ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
+                         (getenv("DPPM_DISABLE_W4") == nullptr ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
                           (w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
                            w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)))));
   float* naff = fuse_norm ? c.at(w.naff) : nullptr;

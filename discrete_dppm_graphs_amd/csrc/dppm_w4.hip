@@ -38,6 +38,34 @@ __device__ __forceinline__ void w4_mma4(floatx4 (&acc)[4], const uintx4 (&wh)[4]
   }
 }
 
+// The same for a wave that owns two 16-channel blocks: every X fragment feeds both (six MFMAs per pair of LDS reads).  The order
+// reads-then-MFMAs is pinned, or the scheduler hoists a tile's worth of reads over the accumulators' registers.
+template <int NS, bool W_IS_A>
+__device__ __forceinline__ void w4_mma8(floatx4 (&acc)[2][4], const uintx4 (&wh)[2][4], const uintx4 (&wl)[2][4], const char* __restrict__ T, const W3Addr& ad) {
+  uintx4 xh = *reinterpret_cast<const uintx4*>(T + w3_off(ad, 0, 0)), xl = xh;
+  if (NS > 1) xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, 0, 0));
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    const int s = n >> 2, j = n & 3;
+    const uintx4 ch_ = xh, cl_ = xl;
+    if (n + 1 < 16) {
+      const unsigned off = w3_off(ad, (n + 1) & 3, (n + 1) >> 2);
+      xh = *reinterpret_cast<const uintx4*>(T + off);
+      if (NS > 1) xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
+      __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      if (NS > 1) {
+        acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], cl_, acc[cb][j]) : w3_mfma(cl_, wh[cb][s], acc[cb][j]);
+        acc[cb][j] = W_IS_A ? w3_mfma(wl[cb][s], ch_, acc[cb][j]) : w3_mfma(ch_, wl[cb][s], acc[cb][j]);
+      }
+      acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], ch_, acc[cb][j]) : w3_mfma(ch_, wh[cb][s], acc[cb][j]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NS > 1 ? 6 : 2, 0);
+  }
+}
+
 // Y = W1 X1 + W2 norm(X2) + b per 64-position tile (model/ppgn.py:66-69: m4 on cat(mm, x)); NRM: X2 is staged through its instance
 // norm (a.aff) and the result's masked per-tile statistics are written (a.stat, a.cnt), see WsArgs in dppm_wstat.h.
 // X tiles in stream order: q = 2 i + s (tile i of this workgroup, source s); tile q travels in register set q % 3 and lands in
@@ -162,10 +190,10 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
 }
 
 // Fused MLP  out = (W2 LeakyReLU(W1 norm(X) + b1) + b2) * mask  (model/ppgn.py:58-59), one job (m1 or m2) per workgroup.
-// Stagers: X tiles (NRM: through the source's instance norm, a.aff) and the tile's mask row.  Multipliers hold both matrices'
-// fragments; per barrier interval they finish tile i-1 (second product from the hidden image H[(i-1) & 1], bias, mask, 16-byte
-// stores) and start tile i (first product from X[i & 1], bias, LeakyReLU, split into the hidden image H[i & 1]): one barrier
-// per tile, X and H double-buffered.  Tile i travels in register set i % 3.
+// Stagers (waves 0-7): X tiles (NRM: through the source's instance norm, a.aff) and the tile's mask row.  Per barrier interval
+// waves 8-11 start tile i (first product from X[i & 1], bias, LeakyReLU, split into the hidden image H[i & 1]) while waves 12-15
+// finish tile i-1 (second product from H[(i-1) & 1], bias, mask, 16-byte stores): one barrier per tile, X and H double-buffered.
+// Tile i travels in the stagers' register set i % 3.
 template <int NS, bool NRM>
 __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
@@ -239,26 +267,62 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   }
 
   // -------------------------------------------------------------------------------------------------- multipliers
-  uintx4 w1h[4], w1l[4], w2h[4], w2l[4];
-  w3_load_w<NS, false>(w1h, w1l, J.W1, J.ldw1, ch, g);
-  w3_load_w<NS, false>(w2h, w2l, J.W2, J.ldw2, ch, g);
-  float b1v[4];                                              // first product: the lane's channels 16 w8 + 4 g + r
+  // Waves 8-11 take the first product, waves 12-15 the second; each owns 32 channels (two 16-channel blocks), so that one X
+  // fragment read from LDS feeds six MFMAs instead of three: with 16 channels per wave the matrix pipe (45 % busy) and the LDS
+  // (47 %) took turns inside every wave (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES / SQ_LDS_IDX_ACTIVE of w3_mlp_kernel).
+  const int second = (wave >> 2) & 1, pw = wave & 3;         // product, channel group 32 pw ..
+  uintx4 wh[2][4], wl[2][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) b1v[r] = J.b1 ? J.b1[16 * w8 + 4 * g + r] : 0.f;
-  const float b2v = J.b2 ? J.b2[ch] : 0.f;                   // second product: channel ch
+  for (int cb = 0; cb < 2; ++cb)
+    w3_load_w<NS, false>(wh[cb], wl[cb], second ? J.W2 : J.W1, second ? J.ldw2 : J.ldw1, 32 * pw + 16 * cb + ci, g);
   const W3Addr ad = w3_addr(ci, g);
-  const unsigned hbase = ci * 256 + (g & 1) * 8, hchunk = (2 * w8 + (g >> 1)) ^ ci;
-  const unsigned r0 = (unsigned)ch * P + 4 * g;
-  const unsigned m0 = 4 * g;
   __syncthreads();                                           // tile 0 is in X[0]
+  if (!second) {
+    // first product, D = W1 X: the lane holds channels 32 pw + 16 cb + 4 g + r of position 16 j + ci -> hidden image
+    const unsigned hbase = ci * 256 + (g & 1) * 8;
+    for (int i = 0; i <= nloc; ++i) {
+      if (i < nloc) {
+        char* Hb = Hs + (i & 1) * BUF;
+        floatx4 acc[2][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        w4_mma8<NS, true>(acc, wh, wl, Xs + (i & 1) * BUF, ad);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const float4 b1 = J.b1 ? *reinterpret_cast<const float4*>(J.b1 + 32 * pw + 16 * cb + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const unsigned hchunk = (unsigned)(2 * (2 * pw + cb) + (g >> 1)) ^ (unsigned)ci;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned h01, l01 = 0, h23, l23 = 0;
+            w3_split2<NS>(ws_leaky(acc[cb][j][0] + b1.x), ws_leaky(acc[cb][j][1] + b1.y), h01, l01);
+            w3_split2<NS>(ws_leaky(acc[cb][j][2] + b1.z), ws_leaky(acc[cb][j][3] + b1.w), h23, l23);
+            const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
+            *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
+            if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // second product, D = H^T W2^T: the lane holds positions 16 j + 4 g + r of channel 32 pw + 16 cb + ci -> bias, mask, 16-byte stores
+  float b2v[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) b2v[cb] = J.b2 ? J.b2[32 * pw + 16 * cb + ci] : 0.f;
+  const unsigned m0 = 4 * g;
   for (int i = 0; i <= nloc; ++i) {
     if (i >= 1) {                                            // finish tile i-1
       const int t = who.rank + (i - 1) * who.per_job;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
-      floatx4 acc[4];
+      floatx4 acc[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      w4_mma4<NS, false>(acc, w2h, w2l, Hs + ((i - 1) & 1) * BUF, ad);
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      w4_mma8<NS, false>(acc, wh, wl, Hs + ((i - 1) & 1) * BUF, ad);
       const float* Mb = Ms + ((i - 1) & 3) * 64;
       float* Yt = J.Y + (size_t)b * J.y_bs + p0;
       const int lim = P - p0;
@@ -266,28 +330,14 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
       for (int j = 0; j < 4; ++j) {
         const int pj = (int)m0 + 16 * j;
         if (pj < lim) {
-          float4 v = ws_f4(acc[j]);
-          v.x += b2v; v.y += b2v; v.z += b2v; v.w += b2v;
           const float4 m = *reinterpret_cast<const float4*>(Mb + pj);
-          v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-          *reinterpret_cast<float4*>(Yt + r0 + 16 * j) = v;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            float4 v = ws_f4(acc[cb][j]);
+            v.x = (v.x + b2v[cb]) * m.x; v.y = (v.y + b2v[cb]) * m.y; v.z = (v.z + b2v[cb]) * m.z; v.w = (v.w + b2v[cb]) * m.w;
+            *reinterpret_cast<float4*>(Yt + (size_t)(32 * pw + 16 * cb + ci) * P + pj) = v;
+          }
         }
-      }
-    }
-    if (i < nloc) {                                          // start tile i
-      char* Hb = Hs + (i & 1) * BUF;
-      floatx4 acc[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      w4_mma4<NS, true>(acc, w1h, w1l, Xs + (i & 1) * BUF, ad);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned h01, l01 = 0, h23, l23 = 0;
-        w3_split2<NS>(ws_leaky(acc[j][0] + b1v[0]), ws_leaky(acc[j][1] + b1v[1]), h01, l01);
-        w3_split2<NS>(ws_leaky(acc[j][2] + b1v[2]), ws_leaky(acc[j][3] + b1v[3]), h23, l23);
-        const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
-        *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
-        if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
       }
     }
     __syncthreads();

@@ -541,12 +541,13 @@ def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 3e-2)])
-@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (1, 130, 2), (6, 64, 2), (40, 24, 2)])
+@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (1, 130, 2), (6, 64, 2), (40, 24, 2), (300, 20, 2)])
 def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
     """Split modes, H = 128: the masked instance norm (util/model_helper.py:176-191) folded into m4's epilogue (per-tile statistics),
     norm_finalize_kernel and the consumers' staging, against the same forward with the stand-alone norm pass
     (DPPM_DISABLE_NORMFUSE=1): ragged graphs (masked positions hold unnormalised values inside the fused path and must not leak),
-    several graphs per workgroup run, a batch (40 x N=24) whose tile runs would span too many graphs and falls back by itself."""
+    several graphs per workgroup run, batches (40 x N=24, 300 x N=20) whose tile runs span more graphs than the LDS tables of
+    dppm_wsplit.h hold: the MLP pair then goes to the role-split kernel (dppm_w4.hip), which reads the (scale, shift) pairs per tile."""
     from oracle import ppgn as op
     H = 128
     rng = np.random.default_rng(1200 + N + L)
