@@ -4,8 +4,9 @@
 
 namespace dppm {
 
-// C[g] = A[g] * B[g] * scale[g / div] (* mask) for g < batch, planes [n][ld] (model/ppgn.py:62-64).  ns: 3 = bf16x3, 1 = bf16.
-bool plane4_ok(const PlaneArgs& a, int batch);
-int plane4_run(const PlaneArgs& a, int batch, int ns, hipStream_t st);
+// C[g] = op(A[g]) * op(B[g]) * scale[g / div] (* mask) for g < batch, planes [n][ld] (model/ppgn.py:62-64 and its backward forms).
+// ns: 3 = bf16x3, 1 = bf16 (forward form only); 6 = three bf16 pieces, six products: float32-equivalent, ta / tb allowed (not both).
+bool plane4_ok(const PlaneArgs& a, int batch, int ns, bool ta, bool tb);
+int plane4_run(const PlaneArgs& a, int batch, int ns, bool ta, bool tb, hipStream_t st);
 
 }  // namespace dppm

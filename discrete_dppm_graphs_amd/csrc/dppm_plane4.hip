@@ -1,5 +1,5 @@
 // Per-channel N x N contraction C[g] = A[g] * B[g] * scale (model/ppgn.py:62-64), split-bf16 arithmetic, 129 <= N <= 512:
-// the role-split, persistent form of dppm_planesplit.h (same LDS images, same MFMA operand order, same results bit for bit).
+// the role-split, persistent form of dppm_planesplit.h (same arithmetic in the same order: same results bit for bit).
 //
 // plane3_kernel lets all 16 waves stage a K = 32 panel AND multiply the previous one: one panel (53 KB) in flight per CU, and
 // only between its request and its landing -- at ~2 us of HBM latency under load that duty cycle, not the matrix pipe (19 %
@@ -12,6 +12,13 @@
 //                            112 accumulator registers at 3 waves per SIMD (168 registers) -- read fragments from LDS, and at a
 //                            plane's last panel scale and store their tiles with 16-byte stores while the stagers go on.
 // One barrier per panel; LDS: two panel stages (106 KB at N = 200).
+//
+// NS = 6 (training, "float32" precision): three bf16 pieces per operand (x = hi + mid + lo, 24 mantissa bits) and the six products
+// down to 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; smallest first, float32 accumulation) -- the split that
+// dppm_wgrad.h uses for the weight gradients -- at 6/16 of the matrix time of v_mfma_f32_16x16x4_f32, which the exact-f32
+// kernel of dppm_planemm.h spends 48 % of its peak on.  The backward forms come with it: dA = dC B^T (TB) and dB = A^T dC (TA)
+// only change which operand is copied straight (k along its rows) and which is transposed while staging.  Three images per
+// operand fill the LDS at N <= 208 (2 x 2 x 3 x 13 KB = 156 KB); larger planes keep the exact-f32 kernel.
 #include "dppm_plane4.h"
 #include "dppm_planesplit.h"
 
@@ -47,13 +54,41 @@ __device__ __forceinline__ P4Work p4_work() {
   return w;
 }
 
-template <int VA, int VB>
-struct P4Pre { float4 a[VA]; float4 b[VB][4]; };
+// Image layout [row][32 k] of dppm_planesplit.h (64-byte rows, 16-byte chunk c of row r at chunk c ^ ((-(r >> 2)) & 3)) with one
+// change: rows r and r ^ 1 trade places where bit 4 of r is set.  A transposing staging thread writes 8 bytes (4 consecutive k) of
+// rows 4 nq + c; with the thread's k quad parity in lane bit 0 and nq in the bits above, the 16 lanes of a ds_write_b64 group
+// differ in the 8-byte half (k quad parity), the chunk (nq & 3) and the 64-byte half of the 128-byte bank span (row bit 0 ^ nq
+// bit 2): 16 distinct slots, conflict-free (it was 4-way: 31 % of plane3's LDS cycles were conflict cycles).  Fragment reads see
+// rows ci ^ (tile & 1) of tile `tile`: the same address set per ds_read_b128 lane group, still conflict-free.
+__device__ __forceinline__ unsigned p4_off(unsigned row, unsigned c) { return ((row ^ ((row >> 4) & 1u)) * 64) + ((c ^ ((0u - (row >> 2)) & 3u)) << 4); }
+
+template <int NX, int NY>
+struct P4Pre { float4 x[NX]; float4 y[NY]; };   // one panel in flight per staging thread: A-side and B-side pieces
+
+template <int NS> struct P4Img { static constexpr int N = NS == 1 ? 1 : NS == 3 ? 2 : 3; };
+
+// four consecutive k of one image row -> 8 bytes in each piece image
+template <int NS>
+__device__ __forceinline__ void p4_put(char* __restrict__ img, unsigned off, int img_bytes, float x0, float x1, float x2, float x3) {
+  if (NS == 6) {
+    const unsigned h01 = w3_pack(x0, x1), h23 = w3_pack(x2, x3);
+    const float r0 = x0 - __uint_as_float(h01 << 16), r1 = x1 - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = x2 - __uint_as_float(h23 << 16), r3 = x3 - __uint_as_float(h23 & 0xffff0000u);
+    const unsigned m01 = w3_pack(r0, r1), m23 = w3_pack(r2, r3);
+    const unsigned l01 = w3_pack(r0 - __uint_as_float(m01 << 16), r1 - __uint_as_float(m01 & 0xffff0000u));
+    const unsigned l23 = w3_pack(r2 - __uint_as_float(m23 << 16), r3 - __uint_as_float(m23 & 0xffff0000u));
+    *reinterpret_cast<uint2*>(img + off) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(img + img_bytes + off) = make_uint2(m01, m23);
+    *reinterpret_cast<uint2*>(img + 2 * img_bytes + off) = make_uint2(l01, l23);
+  } else {
+    p3_put<NS>(img, off, img_bytes, x0, x1, x2, x3);
+  }
+}
 
 template <int NT, int NS, int NR, int NC>
 __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds, int r0, int c0, int lane, int nloc, int np, int dbg, const P4Work& wk) {
   using Cfg = P4Cfg<NT>;
-  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int NIMG = P4Img<NS>::N;
   constexpr int OPB = NIMG * Cfg::IMG, STAGE = 2 * OPB;
   const int n = p.n, ld = p.ld;
   const size_t plane = (size_t)n * ld;
@@ -61,8 +96,10 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
   const int wcols = ld - wk.nlo < Cfg::ROWS ? ld - wk.nlo : Cfg::ROWS;   // ld % 4 == 0, nlo % 16 == 0: whole float4s
   const size_t boff = (size_t)wk.mlo * ld + wk.nlo;
   const int ci = lane & 15, gq = lane >> 4;
-  // p3_off(16 t + ci, gq) = 1024 t + p3_off(ci, gq): one lane offset, tile offsets as immediates
-  const unsigned abase = p3_off(ci, gq) + r0 * 1024, bbase = OPB + p3_off(ci, gq) + c0 * 1024;
+  // p4_off(16 t + ci, gq) = 1024 t + p4_off(ci ^ (t & 1), gq): two lane offsets (even / odd tiles), tile offsets as immediates
+  const unsigned lo_e = p4_off(ci, gq), lo_o = p4_off(ci ^ 1, gq);
+  const unsigned abase0 = ((r0 & 1) ? lo_o : lo_e) + r0 * 1024, abase1 = ((r0 & 1) ? lo_e : lo_o) + r0 * 1024;   // tiles r0 + even / odd
+  const unsigned bbase0 = OPB + ((c0 & 1) ? lo_o : lo_e) + c0 * 1024, bbase1 = OPB + ((c0 & 1) ? lo_e : lo_o) + c0 * 1024;
   floatx4 acc[NR][NC];
 #pragma unroll
   for (int i = 0; i < NR; ++i)
@@ -92,23 +129,45 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
       if (!(dbg & 1)) {
         // fragments one (row tile, column tile) step ahead of the MFMAs that use them; the order is pinned (sched_group_barrier) so
         // that the scheduler does not hoist a panel's worth of reads over the accumulators' registers
-        constexpr bool AHEAD = NR * NC <= 28;                 // 32 tiles: no registers left for the second fragment set
-        if (AHEAD) {
-        uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase), al = ah;
-        if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase);
-        uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase), bl = bh;
-        if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase);
+        constexpr bool AHEAD = NR * NC <= 28 && NS != 6;      // 32 tiles, three pieces: no registers left for a second fragment set
+        if (NS == 6) {
+#pragma unroll
+        for (int ii = 0; ii < NR; ++ii) {
+          const uintx4 ah = *reinterpret_cast<const uintx4*>(st + ((ii & 1) ? abase1 : abase0) + ii * 1024);
+          const uintx4 am = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + ((ii & 1) ? abase1 : abase0) + ii * 1024);
+          const uintx4 al = *reinterpret_cast<const uintx4*>(st + 2 * Cfg::IMG + ((ii & 1) ? abase1 : abase0) + ii * 1024);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const uintx4 bh = *reinterpret_cast<const uintx4*>(st + ((j & 1) ? bbase1 : bbase0) + j * 1024);
+            const uintx4 bm = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + ((j & 1) ? bbase1 : bbase0) + j * 1024);
+            const uintx4 bl = *reinterpret_cast<const uintx4*>(st + 2 * Cfg::IMG + ((j & 1) ? bbase1 : bbase0) + j * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            acc[ii][j] = w3_mfma(bm, am, acc[ii][j]);             // smallest terms first
+            acc[ii][j] = w3_mfma(bh, al, acc[ii][j]);
+            acc[ii][j] = w3_mfma(bl, ah, acc[ii][j]);
+            acc[ii][j] = w3_mfma(bh, am, acc[ii][j]);
+            acc[ii][j] = w3_mfma(bm, ah, acc[ii][j]);
+            acc[ii][j] = w3_mfma(bh, ah, acc[ii][j]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          }
+        }
+        } else if (AHEAD) {
+        uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase0), al = ah;
+        if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase0);
+        uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase0), bl = bh;
+        if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase0);
 #pragma unroll
         for (int t = 0; t < NR * NC; ++t) {
           const int ii = t / NC, j = t % NC;
           const uintx4 cah = ah, cal = al, cbh = bh, cbl = bl;
           if (t + 1 < NR * NC) {
             const int in = (t + 1) / NC, jn = (t + 1) % NC;
-            bh = *reinterpret_cast<const uintx4*>(st + bbase + jn * 1024);
-            if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase + jn * 1024);
+            bh = *reinterpret_cast<const uintx4*>(st + ((jn & 1) ? bbase1 : bbase0) + jn * 1024);
+            if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + ((jn & 1) ? bbase1 : bbase0) + jn * 1024);
             if (jn == 0) {
-              ah = *reinterpret_cast<const uintx4*>(st + abase + in * 1024);
-              if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase + in * 1024);
+              ah = *reinterpret_cast<const uintx4*>(st + ((in & 1) ? abase1 : abase0) + in * 1024);
+              if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + ((in & 1) ? abase1 : abase0) + in * 1024);
             }
             if (jn == 0) __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 4 : 2, 0);
             else __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
@@ -123,15 +182,15 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
         } else {
 #pragma unroll
         for (int ii = 0; ii < NR; ++ii) {
-          const uintx4 ah = *reinterpret_cast<const uintx4*>(st + abase + ii * 1024);
+          const uintx4 ah = *reinterpret_cast<const uintx4*>(st + ((ii & 1) ? abase1 : abase0) + ii * 1024);
           uintx4 al = ah;
-          if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + abase + ii * 1024);
+          if (NS > 1) al = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + ((ii & 1) ? abase1 : abase0) + ii * 1024);
           __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
 #pragma unroll
           for (int j = 0; j < NC; ++j) {
-            const uintx4 bh = *reinterpret_cast<const uintx4*>(st + bbase + j * 1024);
+            const uintx4 bh = *reinterpret_cast<const uintx4*>(st + ((j & 1) ? bbase1 : bbase0) + j * 1024);
             uintx4 bl = bh;
-            if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + bbase + j * 1024);
+            if (NS > 1) bl = *reinterpret_cast<const uintx4*>(st + Cfg::IMG + ((j & 1) ? bbase1 : bbase0) + j * 1024);
             __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
             if (NS > 1) {
               acc[ii][j] = w3_mfma(bl, ah, acc[ii][j]);
@@ -149,11 +208,11 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
   }
 }
 
-template <int NT, int NS, int NBLK>
+template <int NT, int NS, int NBLK, bool TA, bool TB>
 __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, int batch, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char lds4[];
   using Cfg = P4Cfg<NT>;
-  constexpr int NIMG = NS > 1 ? 2 : 1;
+  constexpr int NIMG = P4Img<NS>::N;
   constexpr int OPB = NIMG * Cfg::IMG, STAGE = 2 * OPB;
   constexpr int VA = Cfg::VA, VB = Cfg::VB, NQ = Cfg::NQ;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -185,73 +244,88 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
   }
 
   // -------------------------------------------------------------------------------------------------- stagers
+  // An operand is staged either STRAIGHT (image row r = its matrix row, k along that row: float4 along k -> 8 bytes) or
+  // TRANSPOSING (image row = its matrix column, k along the matrix rows: four float4 from rows k .. k+3 -> for each of 4
+  // columns 4 consecutive k = 8 bytes).  A: straight unless TA (C = A^T B); B: transposing unless TB (C = A B^T).
   const size_t plane = (size_t)n * ld;
   const int nrows = n - wk.mlo < Cfg::ROWS ? n - wk.mlo : Cfg::ROWS, ncols = n - wk.nlo < Cfg::ROWS ? n - wk.nlo : Cfg::ROWS;
-  const int wcols = ld - wk.nlo < Cfg::ROWS ? ld - wk.nlo : Cfg::ROWS;
-  const int akq = tid & 7, arow = tid >> 3;                   // A side: k = 4 akq .., rows arow + 32 v
-  int bkq[VB], bnq[VB];                                       // B side: quad e = tid + 256 v -> (k = 4 bkq .., columns 4 bnq ..)
+  const int wrows = ld - wk.mlo < Cfg::ROWS ? ld - wk.mlo : Cfg::ROWS, wcols = ld - wk.nlo < Cfg::ROWS ? ld - wk.nlo : Cfg::ROWS;
+  const int skq = tid & 7, srow = tid >> 3;                   // straight: k = 4 skq .., rows srow + 32 v
+  int tkq[VB], tnq[VB];                                       // transposing: quad e = tid + 256 v -> (k = 4 tkq .., columns 4 tnq ..), parity of tkq = e & 1
 #pragma unroll
-  for (int v = 0; v < VB; ++v) { const int e = tid + P4_STAGERS * v; bkq[v] = e / NQ; bnq[v] = e - bkq[v] * NQ; }
+  for (int v = 0; v < VB; ++v) { const int e = tid + P4_STAGERS * v, h = e >> 1, hq = h / NQ; tkq[v] = (e & 1) + 2 * hq; tnq[v] = h - hq * NQ; }
+  // unconditional, clamped loads (see dppm_wsplit.h): out-of-range threads re-read element 0 and store zeros
+  auto load_straight = [&](float4* dst, const float* M, int nr, int k0) {      // M: first row of the block
+    const int k = k0 + 4 * skq;
+#pragma unroll
+    for (int v = 0; v < VA; ++v) {
+      const int row = srow + 32 * v;
+      dst[v] = *reinterpret_cast<const float4*>(M + (size_t)(row < nr ? row : 0) * ld + (k < ld ? k : 0));
+    }
+  };
+  auto load_transposing = [&](float4* dst, const float* M, int wc, int k0) {   // M: first column of the block
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      const int k = k0 + 4 * tkq[v];
+      const float* b0 = M + ((tkq[v] < 8 && 4 * tnq[v] < wc) ? 4 * tnq[v] : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[4 * v + r] = *reinterpret_cast<const float4*>(b0 + (size_t)(k + r < n ? k + r : 0) * ld);
+    }
+  };
+  auto land_straight = [&](const float4* src, char* img, int nr, int k0) {
+    const int k = k0 + 4 * skq;
+    const bool k0ok = k + 0 < n, k1ok = k + 1 < n, k2ok = k + 2 < n, k3ok = k + 3 < n;
+    const unsigned cb = skq >> 1, hb = (skq & 1) * 8;
+#pragma unroll
+    for (int v = 0; v < VA; ++v) {
+      const int row = srow + 32 * v;
+      if (row < Cfg::ROWS) {
+        const bool r = row < nr;
+        const float4 x = src[v];
+        p4_put<NS>(img, p4_off(row, cb) + hb, Cfg::IMG, r && k0ok ? x.x : 0.f, r && k1ok ? x.y : 0.f, r && k2ok ? x.z : 0.f, r && k3ok ? x.w : 0.f);
+      }
+    }
+  };
+  auto land_transposing = [&](const float4* src, char* img, int nc, int k0) {
+#pragma unroll
+    for (int v = 0; v < VB; ++v) {
+      if (tkq[v] < 8) {
+        const int k = k0 + 4 * tkq[v];
+        const bool k0ok = k + 0 < n, k1ok = k + 1 < n, k2ok = k + 2 < n, k3ok = k + 3 < n;
+        const unsigned cb = tkq[v] >> 1, hb = (tkq[v] & 1) * 8;
+        const int row = 4 * tnq[v];
+        const float4 x0 = src[4 * v], x1 = src[4 * v + 1], x2 = src[4 * v + 2], x3 = src[4 * v + 3];
+        const bool c0 = row + 0 < nc, c1 = row + 1 < nc, c2 = row + 2 < nc, c3 = row + 3 < nc;
+        p4_put<NS>(img, p4_off(row + 0, cb) + hb, Cfg::IMG, c0 && k0ok ? x0.x : 0.f, c0 && k1ok ? x1.x : 0.f, c0 && k2ok ? x2.x : 0.f, c0 && k3ok ? x3.x : 0.f);
+        p4_put<NS>(img, p4_off(row + 1, cb) + hb, Cfg::IMG, c1 && k0ok ? x0.y : 0.f, c1 && k1ok ? x1.y : 0.f, c1 && k2ok ? x2.y : 0.f, c1 && k3ok ? x3.y : 0.f);
+        p4_put<NS>(img, p4_off(row + 2, cb) + hb, Cfg::IMG, c2 && k0ok ? x0.z : 0.f, c2 && k1ok ? x1.z : 0.f, c2 && k2ok ? x2.z : 0.f, c2 && k3ok ? x3.z : 0.f);
+        p4_put<NS>(img, p4_off(row + 3, cb) + hb, Cfg::IMG, c3 && k0ok ? x0.w : 0.f, c3 && k1ok ? x1.w : 0.f, c3 && k2ok ? x2.w : 0.f, c3 && k3ok ? x3.w : 0.f);
+      }
+    }
+  };
+  constexpr int NX = TA ? 4 * VB : VA, NY = TB ? VA : 4 * VB;
+  typedef P4Pre<NX, NY> Pre;
   int ii = 0, ikp = 0;                                        // issue cursor (plane, panel); clamped at the stream's end
-  auto issue = [&](P4Pre<VA, VB>& pre) {
+  auto issue = [&](Pre& pre) {
     if (dbg & 4) return;
     const long g = (long)wk.group + (long)ii * wk.ngroups;
     const int k0 = ikp * P3_BK;
-    const float* A = p.A + g * plane + (size_t)wk.mlo * ld;
-    const float* B = p.B + g * plane + wk.nlo;
-    const int ka = k0 + 4 * akq;
-#pragma unroll
-    for (int v = 0; v < VA; ++v) {
-      const int row = arow + 32 * v;
-      pre.a[v] = *reinterpret_cast<const float4*>(A + (size_t)(row < nrows ? row : 0) * ld + (ka < ld ? ka : 0));
-    }
-#pragma unroll
-    for (int v = 0; v < VB; ++v) {
-      const int k = k0 + 4 * bkq[v];
-      const float* b0 = B + ((bkq[v] < 8 && 4 * bnq[v] < wcols) ? 4 * bnq[v] : 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pre.b[v][r] = *reinterpret_cast<const float4*>(b0 + (size_t)(k + r < n ? k + r : 0) * ld);
-    }
+    const float* A = p.A + g * plane;
+    const float* B = p.B + g * plane;
+    if (TA) load_transposing(pre.x, A + wk.mlo, wrows, k0); else load_straight(pre.x, A + (size_t)wk.mlo * ld, nrows, k0);
+    if (TB) load_straight(pre.y, B + (size_t)wk.nlo * ld, ncols, k0); else load_transposing(pre.y, B + wk.nlo, wcols, k0);
     if (ii < nloc - 1 || ikp < np - 1) { if (++ikp == np) { ikp = 0; ++ii; } }
   };
   int lkp = 0;                                                // landing cursor (panel index inside its plane)
-  auto land = [&](const P4Pre<VA, VB>& pre, char* stage) {
+  auto land = [&](const Pre& pre, char* stage) {
     if (dbg & 2) return;
     const int k0 = lkp * P3_BK;
-    {
-      const int k = k0 + 4 * akq;
-      const bool k0ok = k + 0 < n, k1ok = k + 1 < n, k2ok = k + 2 < n, k3ok = k + 3 < n;
-      const unsigned cb = akq >> 1, hb = (akq & 1) * 8;
-#pragma unroll
-      for (int v = 0; v < VA; ++v) {
-        const int row = arow + 32 * v;
-        if (row < Cfg::ROWS) {
-          const bool r = row < nrows;
-          const float4 x = pre.a[v];
-          p3_put<NS>(stage, p3_off(row, cb) + hb, Cfg::IMG, r && k0ok ? x.x : 0.f, r && k1ok ? x.y : 0.f, r && k2ok ? x.z : 0.f, r && k3ok ? x.w : 0.f);
-        }
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < VB; ++v) {
-      if (bkq[v] < 8) {
-        const int k = k0 + 4 * bkq[v];
-        const bool k0ok = k + 0 < n, k1ok = k + 1 < n, k2ok = k + 2 < n, k3ok = k + 3 < n;
-        const unsigned cb = bkq[v] >> 1, hb = (bkq[v] & 1) * 8;
-        char* img = stage + OPB;
-        const int row = 4 * bnq[v];
-        const float4 x0 = pre.b[v][0], x1 = pre.b[v][1], x2 = pre.b[v][2], x3 = pre.b[v][3];
-        const bool c0 = row + 0 < ncols, c1 = row + 1 < ncols, c2 = row + 2 < ncols, c3 = row + 3 < ncols;
-        p3_put<NS>(img, p3_off(row + 0, cb) + hb, Cfg::IMG, c0 && k0ok ? x0.x : 0.f, c0 && k1ok ? x1.x : 0.f, c0 && k2ok ? x2.x : 0.f, c0 && k3ok ? x3.x : 0.f);
-        p3_put<NS>(img, p3_off(row + 1, cb) + hb, Cfg::IMG, c1 && k0ok ? x0.y : 0.f, c1 && k1ok ? x1.y : 0.f, c1 && k2ok ? x2.y : 0.f, c1 && k3ok ? x3.y : 0.f);
-        p3_put<NS>(img, p3_off(row + 2, cb) + hb, Cfg::IMG, c2 && k0ok ? x0.z : 0.f, c2 && k1ok ? x1.z : 0.f, c2 && k2ok ? x2.z : 0.f, c2 && k3ok ? x3.z : 0.f);
-        p3_put<NS>(img, p3_off(row + 3, cb) + hb, Cfg::IMG, c3 && k0ok ? x0.w : 0.f, c3 && k1ok ? x1.w : 0.f, c3 && k2ok ? x2.w : 0.f, c3 && k3ok ? x3.w : 0.f);
-      }
-    }
+    if (TA) land_transposing(pre.x, stage, nrows, k0); else land_straight(pre.x, stage, nrows, k0);
+    if (TB) land_straight(pre.y, stage + OPB, ncols, k0); else land_transposing(pre.y, stage + OPB, ncols, k0);
     if (++lkp == np) lkp = 0;
   };
 
-  P4Pre<VA, VB> s0, s1;
+  Pre s0, s1;
   issue(s0); issue(s1);                                       // panels 0, 1
   land(s0, lds4);
   issue(s0);                                                  // panel 2
@@ -269,25 +343,28 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
 
 static int p4_dbg() { const char* e = getenv("DPPM_DBG_P4"); return e ? atoi(e) : 0; }   // timing experiments only: results are wrong
 
-template <int NT, int NS, int NBLK>
+template <int NT, int NS, int NBLK, bool TA, bool TB>
 static int plane4_launch_nt(const PlaneArgs& a, int batch, hipStream_t st) {
   static bool attr_set = false;
-  const size_t lds = (size_t)2 * 2 * (NS > 1 ? 2 : 1) * P4Cfg<NT>::IMG;   // stages x operands x images
+  const size_t lds = (size_t)2 * 2 * P4Img<NS>::N * P4Cfg<NT>::IMG;   // stages x operands x images
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane4_kernel<NT, NS, NBLK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane4_kernel<NT, NS, NBLK, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "plane4: cannot raise the dynamic LDS limit to %zu bytes", lds);
     attr_set = true;
   }
   // one workgroup per CU; NBLK = 1: planes dealt round-robin; NBLK = 2: groups of four workgroups (see P4Work), all 256 launched
   const int grid = NBLK == 1 ? (batch < P4_CUS ? batch : P4_CUS) : P4_CUS;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(plane4_kernel<NT, NS, NBLK>), dim3(grid), dim3(P4_THREADS), lds, st, a, batch, p4_dbg());
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(plane4_kernel<NT, NS, NBLK, TA, TB>), dim3(grid), dim3(P4_THREADS), lds, st, a, batch, p4_dbg());
   return check_launch("plane4");
 }
 
-// 129 <= n <= 224: one block per plane; 225 <= n <= 512: 2 x 2 blocks (enough planes to fill the 64 groups)
-bool plane4_ok(const PlaneArgs& a, int batch) {
-  if (a.ld % 4 != 0 || a.ld < a.n || batch <= 0 || (long)batch * a.n * a.ld >= (1L << 40)) return false;
+// ns = 1, 3 (inference, forward form): 129 <= n <= 224 one block per plane; 225 <= n <= 512 2 x 2 blocks (enough planes to fill the
+// 64 groups).  ns = 6 (float32-equivalent, all three forms): 129 <= n <= 208.
+bool plane4_ok(const PlaneArgs& a, int batch, int ns, bool ta, bool tb) {
+  if (a.ld % 4 != 0 || a.ld < a.n || batch <= 0 || (long)batch * a.n * a.ld >= (1L << 40) || (ta && tb)) return false;
   const int nt = cdiv(a.n, 16);
+  if (ns == 6) return nt >= 9 && nt <= 13;
+  if (ta || tb) return false;
   return (nt >= 9 && nt <= 14) || (nt >= 15 && nt <= 32 && batch >= P4_CUS / 8);
 }
 
@@ -295,32 +372,47 @@ template <int NS>
 static int plane4_dispatch(const PlaneArgs& a, int batch, hipStream_t st) {
   const int nt = cdiv(a.n, 16);
   if (nt <= 14) switch (nt) {
-    case 9: return plane4_launch_nt<9, NS, 1>(a, batch, st);
-    case 10: return plane4_launch_nt<10, NS, 1>(a, batch, st);
-    case 11: return plane4_launch_nt<11, NS, 1>(a, batch, st);
-    case 12: return plane4_launch_nt<12, NS, 1>(a, batch, st);
-    case 13: return plane4_launch_nt<13, NS, 1>(a, batch, st);
-    case 14: return plane4_launch_nt<14, NS, 1>(a, batch, st);
+    case 9: return plane4_launch_nt<9, NS, 1, false, false>(a, batch, st);
+    case 10: return plane4_launch_nt<10, NS, 1, false, false>(a, batch, st);
+    case 11: return plane4_launch_nt<11, NS, 1, false, false>(a, batch, st);
+    case 12: return plane4_launch_nt<12, NS, 1, false, false>(a, batch, st);
+    case 13: return plane4_launch_nt<13, NS, 1, false, false>(a, batch, st);
+    case 14: return plane4_launch_nt<14, NS, 1, false, false>(a, batch, st);
     default: break;
   } else switch (cdiv(nt, 2)) {
-    case 8: return plane4_launch_nt<8, NS, 2>(a, batch, st);
-    case 9: return plane4_launch_nt<9, NS, 2>(a, batch, st);
-    case 10: return plane4_launch_nt<10, NS, 2>(a, batch, st);
-    case 11: return plane4_launch_nt<11, NS, 2>(a, batch, st);
-    case 12: return plane4_launch_nt<12, NS, 2>(a, batch, st);
-    case 13: return plane4_launch_nt<13, NS, 2>(a, batch, st);
-    case 14: return plane4_launch_nt<14, NS, 2>(a, batch, st);
-    case 15: return plane4_launch_nt<15, NS, 2>(a, batch, st);
-    case 16: return plane4_launch_nt<16, NS, 2>(a, batch, st);
+    case 8: return plane4_launch_nt<8, NS, 2, false, false>(a, batch, st);
+    case 9: return plane4_launch_nt<9, NS, 2, false, false>(a, batch, st);
+    case 10: return plane4_launch_nt<10, NS, 2, false, false>(a, batch, st);
+    case 11: return plane4_launch_nt<11, NS, 2, false, false>(a, batch, st);
+    case 12: return plane4_launch_nt<12, NS, 2, false, false>(a, batch, st);
+    case 13: return plane4_launch_nt<13, NS, 2, false, false>(a, batch, st);
+    case 14: return plane4_launch_nt<14, NS, 2, false, false>(a, batch, st);
+    case 15: return plane4_launch_nt<15, NS, 2, false, false>(a, batch, st);
+    case 16: return plane4_launch_nt<16, NS, 2, false, false>(a, batch, st);
     default: break;
   }
   return fail(DPPM_E_UNSUPPORTED, "plane4: n=%d outside 129..512", a.n);
 }
 
-int plane4_run(const PlaneArgs& a, int batch, int ns, hipStream_t st) {
+template <bool TA, bool TB>
+static int plane6_dispatch(const PlaneArgs& a, int batch, hipStream_t st) {
+  switch (cdiv(a.n, 16)) {
+    case 9: return plane4_launch_nt<9, 6, 1, TA, TB>(a, batch, st);
+    case 10: return plane4_launch_nt<10, 6, 1, TA, TB>(a, batch, st);
+    case 11: return plane4_launch_nt<11, 6, 1, TA, TB>(a, batch, st);
+    case 12: return plane4_launch_nt<12, 6, 1, TA, TB>(a, batch, st);
+    case 13: return plane4_launch_nt<13, 6, 1, TA, TB>(a, batch, st);
+    default: return fail(DPPM_E_UNSUPPORTED, "plane4: n=%d outside 129..208 for the three-piece split", a.n);
+  }
+}
+
+int plane4_run(const PlaneArgs& a, int batch, int ns, bool ta, bool tb, hipStream_t st) {
+  if (!plane4_ok(a, batch, ns, ta, tb)) return fail(DPPM_E_UNSUPPORTED, "plane4: n=%d ns=%d ta=%d tb=%d batch=%d not supported", a.n, ns, (int)ta, (int)tb, batch);
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  const int rc = ns > 1 ? plane4_dispatch<3>(a, batch, st) : plane4_dispatch<1>(a, batch, st);
+  int rc;
+  if (ns == 6) rc = ta ? plane6_dispatch<true, false>(a, batch, st) : tb ? plane6_dispatch<false, true>(a, batch, st) : plane6_dispatch<false, false>(a, batch, st);
+  else rc = ns > 1 ? plane4_dispatch<3>(a, batch, st) : plane4_dispatch<1>(a, batch, st);
   if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
   return rc;
 }

@@ -889,8 +889,13 @@ int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batc
   static const bool strip_off = getenv("DPPM_DISABLE_STRIPMM") != nullptr;   // A/B switch for measurements
   if (prec != DPPM_PREC_F32 && !ta && !tb && plane3_supported(n) && aligned16(A) && aligned16(Bm) && aligned16(C)) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // forward form on the bf16 pipe (dppm_plane4.hip, dppm_planesplit.h)
-    if (getenv("DPPM_DISABLE_PLANE4") == nullptr && plane4_ok(pa, batch)) return plane4_run(pa, batch, prec == DPPM_PREC_BF16X3 ? 3 : 1, st);
+    const int ns = prec == DPPM_PREC_BF16X3 ? 3 : 1;
+    if (getenv("DPPM_DISABLE_PLANE4") == nullptr && plane4_ok(pa, batch, ns, false, false)) return plane4_run(pa, batch, ns, false, false, st);
     return prec == DPPM_PREC_BF16X3 ? plane3_launch<3>(pa, batch, st) : plane3_launch<1>(pa, batch, st);
+  }
+  if (prec == DPPM_PREC_F32 && aligned16(A) && aligned16(Bm) && aligned16(C) && getenv("DPPM_DISABLE_PLANE6") == nullptr) {
+    PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // float32-equivalent three-piece split on the bf16 pipe, all three forms (dppm_plane4.hip)
+    if (plane4_ok(pa, batch, 6, ta, tb)) return plane4_run(pa, batch, 6, ta, tb, st);
   }
   if (plane_mm_supported(n) && !strip_off && aligned16(A) && aligned16(Bm) && aligned16(C)) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};

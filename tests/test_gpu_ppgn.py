@@ -281,6 +281,37 @@ def test_plane_matmul_variants(ops, n):
         assert np.all(out[:, :, n:] == 0)
 
 
+@pytest.mark.parametrize("n,batch", [(129, 5), (150, 300), (200, 520), (203, 70), (208, 257)])
+def test_plane_matmul_three_piece_split(ops, n, batch, monkeypatch):
+    """float32 precision, 129 <= N <= 208: the contraction and its two backward forms run on the bf16 pipe with three pieces per
+    operand and six products (dppm_plane4.hip, NS = 6).  Against float64, and against the exact-f32 MFMA kernel of dppm_planemm.h
+    (DPPM_DISABLE_PLANE6=1) on the same inputs: the split must be about as close to float64 as exact float32 is."""
+    rng = np.random.default_rng(n * 3 + batch)
+    ld = (n + 3) // 4 * 4
+    A = np.zeros((batch, n, ld), np.float32)
+    Bm = np.zeros((batch, n, ld), np.float32)
+    A[:, :, :n] = rng.normal(size=(batch, n, n)) * rng.uniform(0.1, 10, size=(batch, 1, 1))
+    Bm[:, :, :n] = rng.normal(size=(batch, n, n))
+    scale = rng.uniform(0.5, 2, size=batch).astype(np.float32)
+    sel = rng.choice(batch, size=min(batch, 6), replace=False)
+    a64, b64 = A[sel, :, :n].astype(np.float64), Bm[sel, :, :n].astype(np.float64)
+    for ta, tb, ref in ((0, 0, a64 @ b64), (1, 0, a64.transpose(0, 2, 1) @ b64), (0, 1, a64 @ b64.transpose(0, 2, 1))):
+        ref = ref * scale[sel, None, None]
+        monkeypatch.delenv("DPPM_DISABLE_PLANE6", raising=False)
+        out = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1).cpu().numpy()
+        monkeypatch.setenv("DPPM_DISABLE_PLANE6", "1")
+        f32 = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1).cpu().numpy()
+        monkeypatch.delenv("DPPM_DISABLE_PLANE6", raising=False)
+        assert np.all(out[:, :, n:] == 0)
+        mag = np.abs(ref).max(axis=(1, 2), keepdims=True)
+        e6 = (np.abs(out[sel, :, :n] - ref) / mag).max()
+        e32 = (np.abs(f32[sel, :, :n] - ref) / mag).max()
+        assert e6 <= 2 * e32 + 2e-7, (ta, tb, e6, e32)
+        close(out[sel, :, :n], ref, tol=1e-5)
+        # every plane, not only the float64 sample: the two float32 paths agree to rounding
+        assert np.abs(out - f32).max() <= 1e-5 * np.abs(f32).max()
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("n", [129, 144, 200, 203, 256, 257, 300, 512])
 def test_plane_matmul_reduced_precision(ops, n, precision, tol):
