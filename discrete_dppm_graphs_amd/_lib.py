@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdppm_hip.so")
 ABI_VERSION = 3
 
 # DPPM_PREC_* of include/dppm_hip.h
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "f32x6": 3}
 
 c_f32p = C.c_void_p     # device pointers travel as integers
 c_f64p = C.c_void_p

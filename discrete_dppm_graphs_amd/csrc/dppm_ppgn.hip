@@ -716,7 +716,7 @@ inline int ws_lin_p(const WsArgs& a, int nsrc, bool trans, int prec, hipStream_t
   if (prec == DPPM_PREC_BF16) return w3_lin<1>(a, nsrc, trans, st);
   return ws_lin(a, nsrc, trans, st);
 }
-inline bool valid_prec(int prec) { return prec == DPPM_PREC_F32 || prec == DPPM_PREC_BF16X3 || prec == DPPM_PREC_BF16; }
+inline bool valid_prec(int prec) { return prec == DPPM_PREC_F32 || prec == DPPM_PREC_BF16X3 || prec == DPPM_PREC_BF16 || prec == DPPM_PREC_F32X6; }
 
 GemmArgs base_args() {
   GemmArgs a{};
@@ -887,13 +887,13 @@ int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
 int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batch, int n, int ld, bool ta, bool tb,
              const float* scale, const float* mask, int div, int prec = DPPM_PREC_F32) {
   static const bool strip_off = getenv("DPPM_DISABLE_STRIPMM") != nullptr;   // A/B switch for measurements
-  if (prec != DPPM_PREC_F32 && !ta && !tb && plane3_supported(n) && aligned16(A) && aligned16(Bm) && aligned16(C)) {
+  if ((prec == DPPM_PREC_BF16X3 || prec == DPPM_PREC_BF16) && !ta && !tb && plane3_supported(n) && aligned16(A) && aligned16(Bm) && aligned16(C)) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // forward form on the bf16 pipe (dppm_plane4.hip, dppm_planesplit.h)
     const int ns = prec == DPPM_PREC_BF16X3 ? 3 : 1;
     if (getenv("DPPM_DISABLE_PLANE4") == nullptr && plane4_ok(pa, batch, ns, false, false)) return plane4_run(pa, batch, ns, false, false, st);
     return prec == DPPM_PREC_BF16X3 ? plane3_launch<3>(pa, batch, st) : plane3_launch<1>(pa, batch, st);
   }
-  if (prec == DPPM_PREC_F32 && aligned16(A) && aligned16(Bm) && aligned16(C) && getenv("DPPM_DISABLE_PLANE6") == nullptr) {
+  if (prec == DPPM_PREC_F32X6 && aligned16(A) && aligned16(Bm) && aligned16(C) && getenv("DPPM_DISABLE_PLANE6") == nullptr) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // float32-equivalent three-piece split on the bf16 pipe, all three forms (dppm_plane4.hip)
     if (plane4_ok(pa, batch, 6, ta, tb)) return plane4_run(pa, batch, 6, ta, tb, st);
   }
@@ -971,7 +971,7 @@ extern "C" int dppm_mlp_pair_fwd(const float* X, long x_bs, const dppm_ppgn_laye
   DPPM_REQUIRE(H == WS_H || hid1, "dppm_mlp_pair_fwd: H != 128 needs hid1/hid2 as scratch");
   DPPM_REQUIRE(aligned16(X) && aligned16(o1) && aligned16(o2) && x_bs % 4 == 0, "dppm_mlp_pair_fwd: planes must be 16-byte aligned");
   DPPM_REQUIRE(valid_prec(precision), "dppm_mlp_pair_fwd: precision=%d", precision);
-  return mlp_pair(Geo{B, P, as_stream(stream)}, *q, H, X, x_bs, maskp, o1, o2, hid1, hid2, hid1 != nullptr, precision);
+  return mlp_pair(Geo{B, P, as_stream(stream)}, *q, H, X, x_bs, maskp, o1, o2, hid1, hid2, hid1 != nullptr, precision == DPPM_PREC_F32X6 ? DPPM_PREC_F32 : precision);
 }
 
 extern "C" size_t dppm_linear_wgrad_workspace_bytes(int M, int Nw, int B, int P) {
@@ -1004,7 +1004,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
                                  void* stream) {
   DPPM_TRY(check_params(pr, "dppm_ppgn_forward"));
   DPPM_REQUIRE(valid_prec(precision), "dppm_ppgn_forward: precision=%d", precision);
-  const int prec = training ? DPPM_PREC_F32 : precision;   // gradients are taken of the exact-float32 forward
+  const int prec = (training || precision == DPPM_PREC_F32X6) ? DPPM_PREC_F32 : precision;   // gradients are taken of the float32 forward
   DPPM_REQUIRE(A && mask && sigma && logits && workspace, "dppm_ppgn_forward: null pointer");
   DPPM_REQUIRE(B > 0 && N > 0, "dppm_ppgn_forward: B=%d N=%d must be positive", B, N);
   DPPM_REQUIRE(((uintptr_t)workspace & 255) == 0, "dppm_ppgn_forward: workspace must be 256-byte aligned");
@@ -1068,7 +1068,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec,
                       fuse_norm && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
-    DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, prec));
+    DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, training ? DPPM_PREC_F32X6 : prec));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
     if (use_wstat(H)) {
       WsArgs wa{};
@@ -1262,8 +1262,8 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));
     }
     // contraction: do1 = dmm o2^T / sqrt(n) * mask ; do2 = o1^T dmm / sqrt(n) * mask
-    DPPM_TRY(plane_mm(c.st, dmm, o2, do1, B * H, N, w.ld, false, true, c.at(w.inv_norm), maskp, H));
-    DPPM_TRY(plane_mm(c.st, o1, dmm, do2, B * H, N, w.ld, true, false, c.at(w.inv_norm), maskp, H));
+    DPPM_TRY(plane_mm(c.st, dmm, o2, do1, B * H, N, w.ld, false, true, c.at(w.inv_norm), maskp, H, DPPM_PREC_F32X6));
+    DPPM_TRY(plane_mm(c.st, o1, dmm, do2, B * H, N, w.ld, true, false, c.at(w.inv_norm), maskp, H, DPPM_PREC_F32X6));
     // m1 (dy is free again: reuse it for the pre-activation gradient)
     float* dpre = dy;
     const float* dout[2] = {do1, do2}; const float* hid[2] = {hid1, hid2};

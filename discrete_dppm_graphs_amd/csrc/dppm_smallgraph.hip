@@ -215,7 +215,6 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane >> 4, n = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile ownership tests become scalar branches
   const int N = a.N, ld = a.ld, P = a.P, L = a.L;
-  const int ntile = (P + 15) >> 4;
   // the wave owns position tiles w + SG_NW * ti, ti < SG_TPW, as far as they exist (ntile <= 25)
 #define SG_TILE(ti) (w + SG_NW * (ti))
 #define SG_HAS(ti) ((ti) < NTL)

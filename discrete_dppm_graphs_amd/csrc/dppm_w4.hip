@@ -204,8 +204,8 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   float* Ms = reinterpret_cast<float*>(smem4 + 4 * BUF);     // [4][64] mask rows: tile i is written in step i-1 and read in step i+1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 3, w8 = wave & 7;
-  const int g = lane >> 4, ci = lane & 15, ch = 16 * w8 + ci;
+  const int role = wave >> 3;
+  const int g = lane >> 4, ci = lane & 15;
   const WsWho who = ws_who(a.njobs);
   const WsJob& J = a.job[who.jid];
   const int P = a.P, tpp = (P + WS_TP - 1) / WS_TP, ntiles = a.B * tpp;

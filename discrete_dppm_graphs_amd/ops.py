@@ -42,7 +42,7 @@ def _f32c(t):
 
 
 def _prec(precision):
-    """'f32' | 'bf16x3' | 'bf16' -> DPPM_PREC_* (include/dppm_hip.h)."""
+    """'f32' | 'bf16x3' | 'bf16' | 'f32x6' -> DPPM_PREC_* (include/dppm_hip.h)"""
     try:
         return PRECISIONS[precision]
     except KeyError:

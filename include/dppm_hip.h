@@ -37,8 +37,9 @@ extern "C" {
 
 /* Matrix arithmetic of the H = 128 per-position linears and of the per-channel contraction in INFERENCE forwards (operands and results are float32 in HBM
  * in every mode; kernels that have no reduced form use DPPM_PREC_F32 silently; training forward + backward always run
- * DPPM_PREC_F32: through the backward of the instance norms the 2^-16 products of the split form are amplified to
- * ~50x the float32 gradient error, measured in tests/test_gpu_ppgn.py::test_backward_kinkfree_h128):
+ * float32-grade arithmetic (DPPM_PREC_F32, and DPPM_PREC_F32X6 where a kernel has it): through the backward of the instance
+ * norms the 2^-16 products of the two-piece split are amplified to ~50x the float32 gradient error, measured in
+ * tests/test_gpu_ppgn.py::test_backward_kinkfree_h128):
  *   DPPM_PREC_F32     exact float32 products on v_mfma_f32_16x16x4_f32;
  *   DPPM_PREC_BF16X3  each operand split into two bf16 pieces (hi + lo), a product = hi*hi + hi*lo + lo*hi on
  *                     v_mfma_f32_16x16x32_bf16 with float32 accumulation: ~6e-6 of the result's magnitude per Linear,
@@ -47,6 +48,11 @@ extern "C" {
 #define DPPM_PREC_F32 0
 #define DPPM_PREC_BF16X3 1
 #define DPPM_PREC_BF16 2
+/*   DPPM_PREC_F32X6   each operand split into three bf16 pieces (hi + mid + lo = all 24 significand bits), a product = the six
+ *                     terms down to 2^-16 on v_mfma_f32_16x16x32_bf16, float32 accumulation: as close to float64 as exact
+ *                     float32 is, at 6/16 of the f32 matrix time.  dppm_plane_matmul only (129 <= n <= 208, all three
+ *                     forms); what training uses for the contraction and its two gradients.  Elsewhere = DPPM_PREC_F32. */
+#define DPPM_PREC_F32X6 3
 
 const char* dppm_last_error(void);
 /* ABI version, bumped on any signature change. */
@@ -187,7 +193,8 @@ int dppm_ppgn_backward(const dppm_ppgn_params* params_host, const dppm_ppgn_para
 /* C[g] = epilogue(A[g] (MxK) * B[g] (KxN)) for g in [0,batch): the per-channel adjacency contraction
  * (model/ppgn.py:62 `out1 @ out2`), planes [N][ld].  trans_a / trans_b select A^T / B^T (backward).
  * scale (nullable): [batch / scale_div] multiplies the product; mask (nullable): [batch / scale_div][n][ld]
- * multiplies it elementwise.  precision != DPPM_PREC_F32 applies to the forward form (no transposes) with 129 <= n <= 1024. */
+ * multiplies it elementwise.  DPPM_PREC_BF16X3 / DPPM_PREC_BF16 apply to the forward form (no transposes) with 129 <= n <= 1024,
+ * DPPM_PREC_F32X6 to every form with 129 <= n <= 208; other cases run exact float32. */
 int dppm_plane_matmul(const float* A, const float* Bm, float* C, int batch, int n, int ld, int trans_a, int trans_b,
                       const float* scale, const float* mask, int scale_div, int precision, void* stream);
 

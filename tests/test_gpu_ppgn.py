@@ -282,10 +282,10 @@ def test_plane_matmul_variants(ops, n):
 
 
 @pytest.mark.parametrize("n,batch", [(129, 5), (150, 300), (200, 520), (203, 70), (208, 257)])
-def test_plane_matmul_three_piece_split(ops, n, batch, monkeypatch):
-    """float32 precision, 129 <= N <= 208: the contraction and its two backward forms run on the bf16 pipe with three pieces per
-    operand and six products (dppm_plane4.hip, NS = 6).  Against float64, and against the exact-f32 MFMA kernel of dppm_planemm.h
-    (DPPM_DISABLE_PLANE6=1) on the same inputs: the split must be about as close to float64 as exact float32 is."""
+def test_plane_matmul_three_piece_split(ops, n, batch):
+    """precision f32x6 (what training uses), 129 <= N <= 208: the contraction and its two backward forms on the bf16 pipe with three
+    pieces per operand and six products (dppm_plane4.hip, NS = 6).  Against float64, and against the exact-f32 MFMA kernel of
+    dppm_planemm.h (precision f32) on the same inputs: the split must be about as close to float64 as exact float32 is."""
     rng = np.random.default_rng(n * 3 + batch)
     ld = (n + 3) // 4 * 4
     A = np.zeros((batch, n, ld), np.float32)
@@ -297,11 +297,8 @@ def test_plane_matmul_three_piece_split(ops, n, batch, monkeypatch):
     a64, b64 = A[sel, :, :n].astype(np.float64), Bm[sel, :, :n].astype(np.float64)
     for ta, tb, ref in ((0, 0, a64 @ b64), (1, 0, a64.transpose(0, 2, 1) @ b64), (0, 1, a64 @ b64.transpose(0, 2, 1))):
         ref = ref * scale[sel, None, None]
-        monkeypatch.delenv("DPPM_DISABLE_PLANE6", raising=False)
-        out = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1).cpu().numpy()
-        monkeypatch.setenv("DPPM_DISABLE_PLANE6", "1")
-        f32 = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1).cpu().numpy()
-        monkeypatch.delenv("DPPM_DISABLE_PLANE6", raising=False)
+        out = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1, precision="f32x6").cpu().numpy()
+        f32 = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1, precision="f32").cpu().numpy()
         assert np.all(out[:, :, n:] == 0)
         mag = np.abs(ref).max(axis=(1, 2), keepdims=True)
         e6 = (np.abs(out[sel, :, :n] - ref) / mag).max()

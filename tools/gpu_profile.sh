@@ -23,5 +23,8 @@ W=$(find "$OUT/write" -name '*counter_collection.csv' | head -n 1)
 K=$(find "$OUT/kt" -name '*kernel_stats.csv' | head -n 1)
 cp "$K" "$OUT/kernel_stats.csv"
 python3 tools/pmc_aggregate.py "$F" "$W" "$OUT/pmc_traffic.json" 200 128 8 32
+# matrix-pipe and LDS activity per kernel (both precisions: the exact-f32 leg runs too), its own pass
+bash tools/gpu_pmc.sh ${TAG}_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+    bench.py --steps 1 --warmup 0 --levels 2 --train-steps 0 --no-cpu-baseline > /dev/null && cp gpurun_out/pmc_${TAG}_sq/summary.txt "$OUT/pmc_mfma_lds.txt" && echo "sq pass done"
 # the raw per-dispatch CSVs are large; keep only the summaries
 rm -rf "$OUT/fetch" "$OUT/write" "$OUT/kt"

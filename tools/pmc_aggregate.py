@@ -11,7 +11,8 @@ import json
 import sys
 from collections import defaultdict
 
-CLASS_OF = (("ws_mlp_kernel", "wstat_mlp2"), ("w3_mlp_kernel", "wstat_mlp2"), ("ws_lin_kernel<2", "wstat_sum2"), ("w3_lin2_kernel", "wstat_sum2"),
+CLASS_OF = (("ws_mlp_kernel", "wstat_mlp2"), ("w3_mlp_kernel", "wstat_mlp2"), ("w4_mlp_kernel", "wstat_mlp2"), ("w4_lin2_kernel", "wstat_sum2"),
+            ("plane4_kernel", "plane_matmul"), ("ws_lin_kernel<2", "wstat_sum2"), ("w3_lin2_kernel", "wstat_sum2"),
             ("w3_lin_kernel<3, 2", "wstat_sum2"), ("w3_lin_kernel<1, 2", "wstat_sum2"), ("ws_lin_kernel<1", "wstat_cols"),
             ("w3_lin_kernel<3, 1", "wstat_cols"), ("w3_lin_kernel<1, 1", "wstat_cols"),
             ("plane_mm", "plane_matmul"), ("plane3_kernel", "plane_matmul"), ("plane3h_kernel", "plane_matmul"), ("head3_kernel", "head"), ("inorm_fwd", "inorm"), ("gemm_f32_kernel", "linear_gemm"))
