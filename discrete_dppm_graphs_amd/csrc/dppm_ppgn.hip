@@ -674,6 +674,79 @@ __global__ __launch_bounds__(256) void mlp32_bwd_kernel(const float* __restrict_
   }
 }
 
+// Forward of both per-position MLPs of a hidden-32 layer in one pass (32 x 32 matrices, torch [out][in] layout, pitch 32):
+//   out_k = (W1_k LeakyReLU(W0_k x + b0_k) + b1_k) * mask   (model/ppgn.py:58-59),  k = m1, m2 from one read of x.
+// One wave per 16-position tile, the hidden tile chained through registers in the MFMA result layout (as mlp32_bwd_kernel): the
+// layer-by-layer form (four generic GEMM launches) moves 8 plane-sets for these 3.  hid1 / hid2 (nullable): training keeps the
+// hidden activations.
+__global__ __launch_bounds__(256) void mlp32_fwd_kernel(const float* __restrict__ X, long x_bs,
+                                                        const float* __restrict__ W0a, const float* __restrict__ W0b,
+                                                        const float* __restrict__ W1a, const float* __restrict__ W1b,
+                                                        const float* __restrict__ b0a, const float* __restrict__ b0b,
+                                                        const float* __restrict__ b1a, const float* __restrict__ b1b,
+                                                        const float* __restrict__ maskp, float* __restrict__ o1, float* __restrict__ o2,
+                                                        float* __restrict__ hid1, float* __restrict__ hid2, long hs, int P, int B) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int ntile = (P + 15) >> 4;
+  const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (id >= B * ntile) return;
+  const int b = id / ntile, pos = 16 * (id - b * ntile) + n;
+  const bool ok = pos < P;
+  const size_t g = (size_t)b * hs;
+  floatx4 src[2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) src[ci][r] = ok ? X[(size_t)b * x_bs + (size_t)(16 * ci + 4 * q + r) * P + pos] : 0.f;
+  const float mk = (maskp && ok) ? maskp[(size_t)b * P + pos] : 1.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float* W0 = k ? W0b : W0a;
+    const float* W1 = k ? W1b : W1a;
+    const float* b0 = k ? b0b : b0a;
+    const float* b1 = k ? b1b : b1a;
+    float* hid = k ? hid2 : hid1;
+    float* out = k ? o2 : o1;
+    float w0[2][4][2], w1[2][4][2];   // A operand: lane (q, m = n) holds W[16 co + n][16 ci + 4 q + r]
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+          w0[ci][r][co] = W0[(16 * co + n) * 32 + 16 * ci + 4 * q + r];
+          w1[ci][r][co] = W1[(16 * co + n) * 32 + 16 * ci + 4 * q + r];
+        }
+    floatx4 t[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}}, acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) t[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[ci][r][co], src[ci][r], t[co], 0, 0, 0);
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = t[co][r] + (b0 ? b0[16 * co + 4 * q + r] : 0.f);
+        t[co][r] = v > 0.f ? v : kSlope * v;
+        if (hid && ok) hid[g + (size_t)(16 * co + 4 * q + r) * P + pos] = t[co][r];
+      }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[ci][r][co], t[ci][r], acc[co], 0, 0, 0);
+    if (ok) {
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[g + (size_t)(16 * co + 4 * q + r) * P + pos] = (acc[co][r] + (b1 ? b1[16 * co + 4 * q + r] : 0.f)) * mk;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -795,6 +868,16 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
     if (!save_hid && prec == DPPM_PREC_BF16X3) return w3_mlp_forward<3>(wa, c.st);
     if (!save_hid && prec == DPPM_PREC_BF16) return w3_mlp_forward<1>(wa, c.st);
     return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
+  }
+  static const bool mlp32_off = getenv("DPPM_DISABLE_MLP32") != nullptr;   // A/B switch for measurements
+  if (H == 32 && !mlp32_off) {   // hidden-32 networks: both MLPs of the layer in one streaming launch
+    const bool prof = prof_enabled();
+    if (prof) prof_before(c.st);
+    hipLaunchKernelGGL(mlp32_fwd_kernel, dim3(cdiv((long)c.B * cdiv(c.P, 16), 4)), dim3(256), 0, c.st, x, x_bs, (const float*)q.m1_w0, (const float*)q.m2_w0,
+                       (const float*)q.m1_w1, (const float*)q.m2_w1, (const float*)q.m1_b0, (const float*)q.m2_b0, (const float*)q.m1_b1, (const float*)q.m2_b1,
+                       maskp, o1, o2, save_hid ? hid1 : (float*)nullptr, save_hid ? hid2 : (float*)nullptr, hs, c.P, c.B);
+    if (prof) prof_after(c.st, PROF_LINEAR, 8.0 * 32 * 32 * (double)c.P * c.B, (save_hid ? 5.0 : 3.0) * sizeof(float) * 32 * (double)c.P * c.B);
+    return check_launch("mlp32_fwd");
   }
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w1, H, false, hid1, hs, H}, nullptr, q.m1_b1, 0, maskp, nullptr, 0, o1, hs, false));

@@ -13,5 +13,7 @@ run 200 --no-prof --nodes 20 --hidden 32 --layers 6 --levels 16 --batch 32 --ste
 run 200 --no-prof --nodes 60 --hidden 128 --layers 8 --levels 64 --batch 64 --steps 4 --warmup 1 --train-steps 6
 # sbm_200: the headline (BASELINE configs[3])
 run 300 --nodes 200 --hidden 128 --layers 8 --levels 64 --batch 32 --steps 2 --warmup 1 --train-steps 3
+# sbm_200 with the 6 x 32 network (gridsearch variant of configs[3]): the hidden-32 kernels at N > 20
+run 200 --nodes 200 --hidden 32 --layers 6 --levels 64 --batch 32 --steps 2 --warmup 1 --train-steps 3
 # N = 512, batch 64 (BASELINE configs[4]): sampling only (the training workspace would need 480 GB), 2 levels of the chain
 run 300 --nodes 512 --hidden 128 --layers 8 --levels 2 --batch 64 --steps 2 --warmup 1 --train-steps 0
