@@ -107,7 +107,9 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
     for (int j = 0; j < NC; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
   // A finished plane leaves in one burst after its last panel (measured: spreading it over two intervals -- half the row tiles
   // now, half before the next plane's first MFMAs -- was 5 % slower; streaming "nt" stores 40 % slower: the L2 merges the 64-byte
-  // row pieces of neighbouring tiles).
+  // row pieces of neighbouring tiles; a three-stage LDS ring with per-slot landed / consumed counters instead of the panel
+  // barrier, which lets the stagers keep landing and requesting during the burst, was bit-identical and 8 % slower: loads
+  // queue behind the burst in the CU's memory pipeline whoever issues them -- a CU moves ~19 GB/s in either direction here).
   auto store_plane = [&](int i) {
     const long g = (long)wk.group + (long)i * wk.ngroups;
     const float scale = p.scale ? p.scale[g / p.div] : 1.f;
