@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void inlin_kernel(const float* __restrict__ ca
   for (int c = 0; c < H; ++c) {
     const float w0 = w[2 * c], w1 = w[2 * c + 1], bc = bias[c];
     float4 v;
-    v.x = w0 * a.x + w1 * s.x + bc; v.y = w0 * a.y + w1 * s.y + bc; v.z = w0 * a.z + w1 * s.z + bc; v.w = w0 * a.w + w1 * s.w + bc;
+    v.x = ws_inlin(w0, w1, bc, a.x, s.x); v.y = ws_inlin(w0, w1, bc, a.y, s.y); v.z = ws_inlin(w0, w1, bc, a.z, s.z); v.w = ws_inlin(w0, w1, bc, a.w, s.w);
     *reinterpret_cast<float4*>(out + (size_t)c * P) = v;
   }
 }
@@ -842,13 +842,15 @@ int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
 }
 
 // m1, m2: Linear -> LeakyReLU -> Linear, then * mask   (model/ppgn.py:58-59)
+struct InlSrc { const float* w; const float* b; const float* in; long bs; };   // in_lin folded into the consumer (WsArgs::inl_*)
 int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long x_bs, const float* maskp, float* o1, float* o2,
-             float* hid1, float* hid2, bool save_hid, int prec, const float* aff = nullptr) {
+             float* hid1, float* hid2, bool save_hid, int prec, const float* aff = nullptr, const InlSrc* inl = nullptr) {
   const long hs = (long)H * c.P;
   if (use_wstat(H)) {   // weight-stationary fused pair: hidden activations stay in LDS unless training
     WsArgs wa{};
     wa.njobs = 2; wa.maskp = maskp; wa.B = c.B; wa.P = c.P;
     wa.aff = aff;   // split inference forms only (checked by the caller)
+    if (inl) { wa.inl_w = inl->w; wa.inl_b = inl->b; wa.inl_in = inl->in; wa.inl_bs = inl->bs; }
     const float* w0[2] = {q.m1_w0, q.m2_w0}; const float* w1[2] = {q.m1_w1, q.m2_w1};
     const float* b0[2] = {q.m1_b0, q.m2_b0}; const float* b1[2] = {q.m1_b1, q.m2_b1};
     float* out[2] = {o1, o2}; float* hid[2] = {hid1, hid2};
@@ -863,8 +865,9 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
     if (!save_hid && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_mlp_ok(wa)) {
       const int tpp = (c.P + WS_TP - 1) / WS_TP;
       const bool tables_fit = w3_contig_ok((long)c.B * tpp, tpp, (int)(8 * w3_slots(2, (long)c.B * tpp)));
-      if ((aff && !tables_fit) || getenv("DPPM_W4MLP") != nullptr) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
+      if ((aff && !tables_fit) || inl || getenv("DPPM_W4MLP") != nullptr) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
     }
+    if (inl) return fail(DPPM_E_INVALID, "mlp_pair: the in_lin form needs the role-split kernel");
     if (!save_hid && prec == DPPM_PREC_BF16X3) return w3_mlp_forward<3>(wa, c.st);
     if (!save_hid && prec == DPPM_PREC_BF16) return w3_mlp_forward<1>(wa, c.st);
     return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
@@ -1114,10 +1117,6 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
                      w.CT, cat, maskp, c.at(w.inv_norm));
   DPPM_TRY(check_launch("prep"));
 
-  // in_lin: u0 = W_in (H x 2) * [A ; sigma I] + b     (model/ppgn.py:301)
-  hipLaunchKernelGGL(inlin_kernel, dim3(cdiv(P, 1024), B), dim3(256), 0, c.st, cat, cat_bs, pr->in_w, pr->in_b, H, P, c.at(w.u0));
-  DPPM_TRY(check_launch("in_lin"));
-
   // Split modes, H = 128: the instance norm has no pass of its own.  m4 writes its raw result into the layer's CAT slot together
   // with per-tile statistics, norm_finalize_kernel turns them into a (scale, shift) table per graph and channel, and the three
   // consumers of the layer output (next layer's MLP pair and skip input, read-out head) apply it while staging.
@@ -1127,6 +1126,14 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
                          (getenv("DPPM_DISABLE_W4") == nullptr ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
                           (w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
                            w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)))));
+  // in_lin (K = 2) folded into layer 0's consumers: u0 is never written (one plane-set less to write, two less to read per level)
+  const bool fuse_inlin = fuse_norm && getenv("DPPM_DISABLE_W4") == nullptr && getenv("DPPM_DISABLE_INLINFUSE") == nullptr;
+  const InlSrc inl{pr->in_w, pr->in_b, cat, cat_bs};
+  if (!fuse_inlin) {
+    // in_lin: u0 = W_in (H x 2) * [A ; sigma I] + b     (model/ppgn.py:301)
+    hipLaunchKernelGGL(inlin_kernel, dim3(cdiv(P, 1024), B), dim3(256), 0, c.st, cat, cat_bs, pr->in_w, pr->in_b, H, P, c.at(w.u0));
+    DPPM_TRY(check_launch("in_lin"));
+  }
   float* naff = fuse_norm ? c.at(w.naff) : nullptr;
   const size_t aff_sz = (size_t)B * 2 * WS_H;
   if (fuse_norm) {
@@ -1149,7 +1156,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       DPPM_TRY(check_launch("diag_set"));
     }
     DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec,
-                      fuse_norm && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr));
+                      fuse_norm && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr, fuse_inlin && l == 0 ? &inl : nullptr));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
     DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, training ? DPPM_PREC_F32X6 : prec));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
@@ -1164,6 +1171,10 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         wa.aff = naff + (size_t)(l > 0 ? l - 1 : L) * aff_sz;
         wa.stat = c.at(w.nstat); wa.cnt = c.at(w.ncnt); wa.maskstat = maskp;
         { const char* e = getenv("DPPM_DBG"); wa.dbg = e ? atoi(e) : 0; }
+        if (fuse_inlin && l == 0) {   // the skip input u0 is formed while staging
+          wa.inl_w = inl.w; wa.inl_b = inl.b; wa.inl_in = inl.in; wa.inl_bs = inl.bs;
+          if (!w4_lin2_ok(wa)) return fail(DPPM_E_INVALID, "dppm_ppgn_forward: the in_lin form of m4 does not apply");
+        }
       }
       // split inference modes: staging waves / multiplying waves (dppm_w4.hip); DPPM_DISABLE_W4=1 keeps the two-role form of dppm_wsplit.h
       if (!training && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_lin2_ok(wa))

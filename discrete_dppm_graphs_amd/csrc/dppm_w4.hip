@@ -66,11 +66,28 @@ __device__ __forceinline__ void w4_mma8(floatx4 (&acc)[2][4], const uintx4 (&wh)
   }
 }
 
+// in_lin while staging (WsArgs::inl_*): the staging thread's four channels 4 cg .. 4 cg + 3 at its four positions from the two
+// input values of each position
+struct W4Inl { float w0[4], w1[4], b[4]; };
+__device__ __forceinline__ W4Inl w4_inl_load(const WsArgs& a, int tid) {
+  W4Inl r;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int c = 4 * (tid >> 4) + v;
+    r.w0[v] = a.inl_w[2 * c]; r.w1[v] = a.inl_w[2 * c + 1]; r.b[v] = a.inl_b ? a.inl_b[c] : 0.f;
+  }
+  return r;
+}
+__device__ __forceinline__ float4 w4_inl_row(const W4Inl& k, int v, const float4& A, const float4& S) {
+  return make_float4(ws_inlin(k.w0[v], k.w1[v], k.b[v], A.x, S.x), ws_inlin(k.w0[v], k.w1[v], k.b[v], A.y, S.y),
+                     ws_inlin(k.w0[v], k.w1[v], k.b[v], A.z, S.z), ws_inlin(k.w0[v], k.w1[v], k.b[v], A.w, S.w));
+}
+
 // Y = W1 X1 + W2 norm(X2) + b per 64-position tile (model/ppgn.py:66-69: m4 on cat(mm, x)); NRM: X2 is staged through its instance
 // norm (a.aff) and the result's masked per-tile statistics are written (a.stat, a.cnt), see WsArgs in dppm_wstat.h.
 // X tiles in stream order: q = 2 i + s (tile i of this workgroup, source s); tile q travels in register set q % 3 and lands in
 // LDS buffer q & 1.
-template <int NS, bool NRM>
+template <int NS, bool NRM, bool INLIN>
 __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
@@ -93,14 +110,23 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
     const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);   // channels 4 cg .., positions 4 q ..
     const int oc = 4 * (tid & 15);
     int qi = 0, qs = 0;                                      // issue cursor (tile, source)
+    W4Inl inl{};
+    if (INLIN) inl = w4_inl_load(a, tid);
     auto issue = [&](W4Pre& pre) {                           // unconditional clamped loads of the tile at the cursor
       const int t = rank + (qi < nloc ? qi : nloc - 1) * G;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
-      const float* Xt = (qs ? J.X2 + (size_t)b * J.x2_bs : J.X + (size_t)b * J.x_bs) + p0 + ((p0 + oc < P) ? o0 : 0u);
+      const float* Xt;
+      size_t s1 = P, s2 = (size_t)2 * P, s3 = (size_t)3 * P;
+      if (INLIN) {   // source 1 = the two input planes (a: A, b: sigma I; c, d re-read them): pointer and stride selects, no branch
+        Xt = qs ? a.inl_in + (size_t)b * a.inl_bs + p0 + ((p0 + oc < P) ? (unsigned)oc : 0u) : J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);
+        s2 = qs ? 0 : s2; s3 = qs ? s1 : s3;
+      } else {
+        Xt = (qs ? J.X2 + (size_t)b * J.x2_bs : J.X + (size_t)b * J.x_bs) + p0 + ((p0 + oc < P) ? o0 : 0u);
+      }
       pre.a = *reinterpret_cast<const float4*>(Xt);
-      pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
-      pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
-      pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+      pre.b = *reinterpret_cast<const float4*>(Xt + s1);
+      pre.c = *reinterpret_cast<const float4*>(Xt + s2);
+      pre.d = *reinterpret_cast<const float4*>(Xt + s3);
       if (NRM) {
         const float* T = a.aff + (size_t)b * 256 + 4 * (tid >> 4);
         pre.sc = *reinterpret_cast<const float4*>(T);
@@ -116,7 +142,11 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
       const bool in = li < nloc && p0 + oc < P;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
-      if (NRM && ls == 1) {                                  // the skip input's instance norm (uniform branch)
+      if (INLIN && ls == 1) {                                // the skip input is u0 = in_lin(A, sigma I), formed here (uniform branch)
+        const float4 A4 = xa, S4 = xb;
+        xa = w4_inl_row(inl, 0, A4, S4); xb = w4_inl_row(inl, 1, A4, S4); xc = w4_inl_row(inl, 2, A4, S4); xd = w4_inl_row(inl, 3, A4, S4);
+        if (!in) xa = xb = xc = xd = z;
+      } else if (NRM && ls == 1) {                           // the skip input's instance norm (uniform branch)
         w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w);
       }
       w3_tile_store4<NS>(xa, xb, xc, xd, Xs + buf * BUF, tid);
@@ -194,7 +224,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
 // waves 8-11 start tile i (first product from X[i & 1], bias, LeakyReLU, split into the hidden image H[i & 1]) while waves 12-15
 // finish tile i-1 (second product from H[(i-1) & 1], bias, mask, 16-byte stores): one barrier per tile, X and H double-buffered.
 // Tile i travels in the stagers' register set i % 3.
-template <int NS, bool NRM>
+template <int NS, bool NRM, bool INLIN>
 __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
@@ -218,14 +248,22 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
     const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);
     const int oc = 4 * (tid & 15);
     int qi = 0;
+    W4Inl inl{};
+    if (INLIN) inl = w4_inl_load(a, tid);
     auto issue = [&](W4Pre& pre) {
       const int t = who.rank + (qi < nloc ? qi : nloc - 1) * who.per_job;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
+      if (INLIN) {   // the source is u0 = in_lin(A, sigma I): two input planes instead of 128 channels
+        const float* It = a.inl_in + (size_t)b * a.inl_bs + p0 + ((p0 + oc < P) ? (unsigned)oc : 0u);
+        pre.a = *reinterpret_cast<const float4*>(It);
+        pre.b = *reinterpret_cast<const float4*>(It + (size_t)P);
+      } else {
       const float* Xt = J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);
       pre.a = *reinterpret_cast<const float4*>(Xt);
       pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
       pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
       pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+      }
       if (NRM) {
         const float* T = a.aff + (size_t)b * 256 + 4 * (tid >> 4);
         pre.sc = *reinterpret_cast<const float4*>(T);
@@ -241,6 +279,11 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
       const bool in = li < nloc && p0 + oc < P;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+      if (INLIN) {
+        const float4 A4 = pre.a, S4 = pre.b;
+        xa = in ? w4_inl_row(inl, 0, A4, S4) : z; xb = in ? w4_inl_row(inl, 1, A4, S4) : z;
+        xc = in ? w4_inl_row(inl, 2, A4, S4) : z; xd = in ? w4_inl_row(inl, 3, A4, S4) : z;
+      }
       if (NRM) { w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w); }
       w3_tile_store4<NS>(xa, xb, xc, xd, Xs + (li & 1) * BUF, tid);
       if (tid < 64) Ms[(li & 3) * 64 + tid] = (maskp && li < nloc && p0 + lane < P) ? pre.m : (maskp ? 0.f : 1.f);
@@ -346,14 +389,15 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
 
 template <int NS>
 static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
-  static bool set[2] = {false, false};
+  static bool set[3] = {false, false, false};
   const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + 4 * 64 * sizeof(float);
-  const bool nrm = a.aff != nullptr;
-  auto kern = nrm ? w4_mlp_kernel<NS, true> : w4_mlp_kernel<NS, false>;
-  if (!set[nrm]) {
+  const bool nrm = a.aff != nullptr, inl = a.inl_w != nullptr;   // in_lin's output is not normalised: never both
+  const int which = inl ? 2 : (nrm ? 1 : 0);
+  auto kern = inl ? w4_mlp_kernel<NS, false, true> : (nrm ? w4_mlp_kernel<NS, true, false> : w4_mlp_kernel<NS, false, false>);
+  if (!set[which]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "w4_mlp: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set[nrm] = true;
+    set[which] = true;
   }
   const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
   const long slots = w3_slots(a.njobs, ntiles);              // one workgroup per CU: 32 per XCD, jobs that share X on one XCD
@@ -366,6 +410,7 @@ static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
 
 bool w4_mlp_ok(const WsArgs& a) {
   if (a.njobs < 1 || a.njobs > WS_MAX_JOBS || a.P % 4 != 0 || (long)WS_H * a.P >= (1L << 31) || (a.maskp && !ws_al16(a.maskp))) return false;
+  if (a.inl_w && (a.aff || !a.inl_in || !ws_al16(a.inl_in) || a.inl_bs % 4)) return false;
   for (int i = 0; i < a.njobs; ++i) {
     const WsJob& j = a.job[i];
     if (!j.X || !j.W1 || !j.W2 || !j.Y || j.Mid || j.accumulate || !ws_al16(j.X) || !ws_al16(j.Y) || j.x_bs % 4 || j.y_bs % 4) return false;
@@ -380,14 +425,15 @@ int w4_mlp_run(const WsArgs& a, int ns, hipStream_t st) {
 
 template <int NS>
 static int w4_lin2_launch(const WsArgs& a, hipStream_t st) {
-  static bool set[2] = {false, false};
+  static bool set[3] = {false, false, false};
   const size_t lds = (size_t)2 * (NS > 1 ? 2 : 1) * W3_IMG + 2 * 64 * sizeof(float);
-  const bool nrm = a.stat != nullptr;
-  auto kern = nrm ? w4_lin2_kernel<NS, true> : w4_lin2_kernel<NS, false>;
-  if (!set[nrm]) {
+  const bool nrm = a.stat != nullptr, inl = a.inl_w != nullptr;   // the in_lin form always comes with the statistics (layer 0 of the fused-norm forward)
+  const int which = inl ? 2 : (nrm ? 1 : 0);
+  auto kern = inl ? w4_lin2_kernel<NS, true, true> : (nrm ? w4_lin2_kernel<NS, true, false> : w4_lin2_kernel<NS, false, false>);
+  if (!set[which]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "w4_lin2: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set[nrm] = true;
+    set[which] = true;
   }
   const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);       // one workgroup per CU
@@ -400,8 +446,10 @@ static int w4_lin2_launch(const WsArgs& a, hipStream_t st) {
 
 bool w4_lin2_ok(const WsArgs& a) {
   const WsJob& j = a.job[0];
-  return a.njobs == 1 && !a.side && !a.act && !a.maskp && !j.accumulate && j.X && j.X2 && j.W1 && j.W2 && j.Y && ws_al16(j.X) && ws_al16(j.X2) &&
-         ws_al16(j.Y) && j.x_bs % 4 == 0 && j.x2_bs % 4 == 0 && j.y_bs % 4 == 0 && a.P % 4 == 0 && (long)WS_H * a.P < (1L << 31) &&
+  const bool inl = a.inl_w != nullptr;
+  if (inl && !(a.inl_in && ws_al16(a.inl_in) && a.inl_bs % 4 == 0 && a.stat)) return false;
+  return a.njobs == 1 && !a.side && !a.act && !a.maskp && !j.accumulate && j.X && (inl || j.X2) && j.W1 && j.W2 && j.Y && ws_al16(j.X) && (inl || ws_al16(j.X2)) &&
+         ws_al16(j.Y) && j.x_bs % 4 == 0 && (inl || j.x2_bs % 4 == 0) && j.y_bs % 4 == 0 && a.P % 4 == 0 && (long)WS_H * a.P < (1L << 31) &&
          (a.stat == nullptr || (a.aff && a.cnt && a.maskstat));
 }
 

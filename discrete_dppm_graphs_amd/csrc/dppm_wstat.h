@@ -67,8 +67,15 @@ struct WsArgs {
   //          [B][P]); norm_finalize_kernel merges the tiles of a graph into the next aff table.
   const float* aff;
   float* stat; float* cnt; const float* maskstat;
+  // in_lin folded into layer 0's consumers (role-split kernels of dppm_w4.hip): when inl_w is set, the 128-channel source (fused MLP:
+  // X; two-source Linear: X2) is not read but formed while staging, u0[c][p] = inl_w[c][0] * in[b][0][p] + inl_w[c][1] * in[b][1][p]
+  // + inl_b[c] (model/ppgn.py:301), from the two input planes inl_in [B][2][P] (A and sigma I).
+  const float* inl_w; const float* inl_b; const float* inl_in; long inl_bs;
   int dbg;                            // timing experiments (DPPM_DBG): bit 0 skips the statistics, bit 1 the affine staging
 };
+
+// one in_lin value; the stand-alone kernel and the staging code of the fused forms share this expression
+__device__ __forceinline__ float ws_inlin(float w0, float w1, float bc, float a, float s) { return w0 * a + w1 * s + bc; }
 
 __device__ __forceinline__ int ws_hoff(int k) { return k * WS_HP + 16 * (k >> 5); }
 

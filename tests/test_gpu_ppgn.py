@@ -568,6 +568,31 @@ def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("B,N,L", [(3, 41, 2), (2, 130, 1), (5, 64, 3), (40, 24, 2)])
+def test_inlin_formed_while_staging(ops, precision, tol, B, N, L):
+    """Split modes, H = 128: layer 0's consumers (MLP pair, m4's skip source) form u0 = in_lin([A, sigma I]) (model/ppgn.py:301) while
+    staging instead of reading it; against the same forward with the stand-alone in_lin kernel (DPPM_DISABLE_INLINFUSE=1).  Ragged
+    last tiles (P not a multiple of 64), padded planes (ld > N), several graphs per workgroup."""
+    from oracle import ppgn as op
+    H = 128
+    rng = np.random.default_rng(77 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 5 * L)
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    os.environ["DPPM_DISABLE_INLINFUSE"] = "1"
+    try:
+        plain, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    finally:
+        del os.environ["DPPM_DISABLE_INLINFUSE"]
+    assert np.isfinite(got).all()
+    close(got, plain, tol=tol)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 3e-2)])
 @pytest.mark.parametrize("B,N,L", [(3, 41, 3), (1, 130, 2), (6, 64, 2), (40, 24, 2), (300, 20, 2)])
 def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
