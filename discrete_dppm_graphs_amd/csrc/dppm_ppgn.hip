@@ -14,6 +14,7 @@
 #include "dppm_wsplit.h"
 #include "dppm_head.h"
 #include "dppm_w4.h"
+#include "dppm_w6.h"
 #include "dppm_plane4.h"
 #include "dppm_wgrad.h"
 #include "dppm_planemm.h"
@@ -785,6 +786,9 @@ inline bool use_wstat(int H) {
 
 // weight-stationary Linear in the requested arithmetic (include/dppm_hip.h DPPM_PREC_*)
 inline int ws_lin_p(const WsArgs& a, int nsrc, bool trans, int prec, hipStream_t st) {
+  // training (DPPM_PREC_F32X6): single-source linears on the bf16 pipe with the three-piece split (dppm_w6.hip); the two-source form
+  // does not fit (two matrices x three pieces = 96 registers beside accumulators and fragments) and stays exact f32
+  if (prec == DPPM_PREC_F32X6 && nsrc == 1 && getenv("DPPM_DISABLE_W6") == nullptr && w6_lin_ok(a, nsrc)) return w6_lin_run(a, nsrc, trans, st);
   if (prec == DPPM_PREC_BF16X3) return w3_lin<3>(a, nsrc, trans, st);
   if (prec == DPPM_PREC_BF16) return w3_lin<1>(a, nsrc, trans, st);
   return ws_lin(a, nsrc, trans, st);
@@ -1233,7 +1237,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     wa.njobs = 1; wa.B = B; wa.P = P; wa.act = 1;
     WsJob& j = wa.job[0];
     j.X = c.at(w.R); j.x_bs = hs; j.W1 = pr->after_w; j.ldw1 = H; j.b1 = pr->after_b; j.Y = c.at(w.act); j.y_bs = hs;
-    DPPM_TRY(ws_lin_p(wa, 1, false, prec, c.st));
+    DPPM_TRY(ws_lin_p(wa, 1, false, training ? DPPM_PREC_F32X6 : prec, c.st));
   } else {
     DPPM_TRY(linear(c, H, LinArgs{pr->after_w, H, false, c.at(w.R), hs, H}, nullptr, pr->after_b, 1, nullptr, nullptr, 0, c.at(w.act), hs, false));
   }
@@ -1246,7 +1250,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
                                   const float* sigma, int B, int N, const float* dlogits, float* dsigma, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   (void)A; (void)mask; (void)sigma;
-  const int prec = DPPM_PREC_F32;
+  const int prec = DPPM_PREC_F32X6;   // float32-grade: exact-f32 MFMAs, or the three-piece split where a kernel has it
   DPPM_TRY(check_params(pr, "dppm_ppgn_backward(params)"));
   DPPM_TRY(check_params(gr, "dppm_ppgn_backward(grads)"));
   DPPM_REQUIRE(dlogits && workspace, "dppm_ppgn_backward: null pointer");

@@ -1,0 +1,12 @@
+// Float32-grade (three bf16 pieces, six products) role-split linears of the H = 128 network for training (dppm_w6.hip).
+#pragma once
+#include "dppm_wstat.h"
+
+namespace dppm {
+
+// Y (+)= epilogue(W1 X [+ W2 X2] + b1) for every job (bias, LeakyReLU, mask, accumulate as ws_lin); trans applies the transposed
+// matrices (data gradients).  No side input, no folded norm.
+bool w6_lin_ok(const WsArgs& a, int nsrc);
+int w6_lin_run(const WsArgs& a, int nsrc, bool trans, hipStream_t st);
+
+}  // namespace dppm
