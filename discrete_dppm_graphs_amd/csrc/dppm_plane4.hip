@@ -115,6 +115,40 @@ __device__ __forceinline__ void p4_multiply(const PlaneArgs& p, const char* lds,
     const float scale = p.scale ? p.scale[g / p.div] : 1.f;
     const float* mask = p.mask ? p.mask + (size_t)(g / p.div) * plane + boff : nullptr;
     float* C = p.C + g * plane + boff;
+    if (NS == 6 && mask) {   // backward forms: the mask pieces of two tiles are requested before the first of them is used
+      constexpr int MG = 2;
+#pragma unroll
+      for (int ii = 0; ii < NR; ++ii) {
+        const int row = (r0 + ii) * 16 + (lane & 15);
+#pragma unroll
+        for (int j0 = 0; j0 < NC; j0 += MG) {
+          float4 mk[MG];
+#pragma unroll
+          for (int jj = 0; jj < MG; ++jj) {
+            const int col = (c0 + j0 + jj) * 16 + 4 * (lane >> 4);
+            if (j0 + jj < NC) mk[jj] = *reinterpret_cast<const float4*>(mask + (size_t)(row < nrows ? row : 0) * ld + (col < wcols ? col : 0));
+          }
+#pragma unroll
+          for (int jj = 0; jj < MG; ++jj) {
+            if (j0 + jj < NC) {
+              const int j = j0 + jj;
+              const int col = (c0 + j) * 16 + 4 * (lane >> 4);
+              if (row < nrows && col < wcols) {
+                float4 v = make_float4(acc[ii][j][0] * scale * mk[jj].x, acc[ii][j][1] * scale * mk[jj].y, acc[ii][j][2] * scale * mk[jj].z, acc[ii][j][3] * scale * mk[jj].w);
+                const int lim = ncols - col;
+                if (lim < 1) v.x = 0.f;
+                if (lim < 2) v.y = 0.f;
+                if (lim < 3) v.z = 0.f;
+                if (lim < 4) v.w = 0.f;
+                *reinterpret_cast<float4*>(C + (size_t)row * ld + col) = v;
+              }
+              acc[ii][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ii = 0; ii < NR; ++ii)
 #pragma unroll

@@ -293,12 +293,15 @@ def test_plane_matmul_three_piece_split(ops, n, batch):
     A[:, :, :n] = rng.normal(size=(batch, n, n)) * rng.uniform(0.1, 10, size=(batch, 1, 1))
     Bm[:, :, :n] = rng.normal(size=(batch, n, n))
     scale = rng.uniform(0.5, 2, size=batch).astype(np.float32)
+    mask = np.zeros((batch, n, ld), np.float32)            # the backward forms of the model multiply by the graph's mask
+    mask[:, :, :n] = rng.random((batch, n, n)) < 0.8
     sel = rng.choice(batch, size=min(batch, 6), replace=False)
     a64, b64 = A[sel, :, :n].astype(np.float64), Bm[sel, :, :n].astype(np.float64)
     for ta, tb, ref in ((0, 0, a64 @ b64), (1, 0, a64.transpose(0, 2, 1) @ b64), (0, 1, a64 @ b64.transpose(0, 2, 1))):
-        ref = ref * scale[sel, None, None]
-        out = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1, precision="f32x6").cpu().numpy()
-        f32 = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), scale_div=1, precision="f32").cpu().numpy()
+        mk = dev(mask) if (ta or tb) else None
+        ref = ref * scale[sel, None, None] * (mask[sel, :, :n] if mk is not None else 1.0)
+        out = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), mask=mk, scale_div=1, precision="f32x6").cpu().numpy()
+        f32 = ops.plane_matmul(dev(A), dev(Bm), n, trans_a=ta, trans_b=tb, scale=dev(scale), mask=mk, scale_div=1, precision="f32").cpu().numpy()
         assert np.all(out[:, :, n:] == 0)
         mag = np.abs(ref).max(axis=(1, 2), keepdims=True)
         e6 = (np.abs(out[sel, :, :n] - ref) / mag).max()
