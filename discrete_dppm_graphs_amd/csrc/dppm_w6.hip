@@ -59,22 +59,35 @@ __device__ __forceinline__ void w6_load_w(uintx4 (&wh)[4], uintx4 (&wm)[4], uint
     }
   }
 }
-// acc[j] += X-tile(positions 16 j ..) x W-slice over K = 128, D = X^T W^T (lane: 4 positions of one channel); fragment reads one
-// (k step, position group) ahead, order pinned
+// acc[j] += X-tile(positions 16 j ..) x W-slice over K = 128, D = X^T W^T (lane: 4 positions of one channel).  AHEAD: fragment reads
+// one (k step, position group) ahead of their MFMAs (12 more registers: the single-source form); the order is pinned either way.
+template <bool AHEAD>
 __device__ __forceinline__ void w6_mma4(floatx4 (&acc)[4], const uintx4 (&wh)[4], const uintx4 (&wm)[4], const uintx4 (&wl)[4],
                                         const char* __restrict__ T, const W3Addr& ad) {
-  uintx4 xh = *reinterpret_cast<const uintx4*>(T + w3_off(ad, 0, 0));
-  uintx4 xm = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, 0, 0));
-  uintx4 xl = *reinterpret_cast<const uintx4*>(T + 2 * W3_IMG + w3_off(ad, 0, 0));
+  uintx4 xh, xm, xl;
+  if (AHEAD) {
+    xh = *reinterpret_cast<const uintx4*>(T + w3_off(ad, 0, 0));
+    xm = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, 0, 0));
+    xl = *reinterpret_cast<const uintx4*>(T + 2 * W3_IMG + w3_off(ad, 0, 0));
+  }
 #pragma unroll
   for (int n = 0; n < 16; ++n) {
     const int s = n >> 2, j = n & 3;
-    const uintx4 ch_ = xh, cm_ = xm, cl_ = xl;
-    if (n + 1 < 16) {
-      const unsigned off = w3_off(ad, (n + 1) & 3, (n + 1) >> 2);
-      xh = *reinterpret_cast<const uintx4*>(T + off);
-      xm = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
-      xl = *reinterpret_cast<const uintx4*>(T + 2 * W3_IMG + off);
+    uintx4 ch_, cm_, cl_;
+    if (AHEAD) {
+      ch_ = xh; cm_ = xm; cl_ = xl;
+      if (n + 1 < 16) {
+        const unsigned off = w3_off(ad, (n + 1) & 3, (n + 1) >> 2);
+        xh = *reinterpret_cast<const uintx4*>(T + off);
+        xm = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
+        xl = *reinterpret_cast<const uintx4*>(T + 2 * W3_IMG + off);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      }
+    } else {
+      const unsigned off = w3_off(ad, j, s);
+      ch_ = *reinterpret_cast<const uintx4*>(T + off);
+      cm_ = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
+      cl_ = *reinterpret_cast<const uintx4*>(T + 2 * W3_IMG + off);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
     }
     acc[j] = w3_mfma(cm_, wm[s], acc[j]);                     // smallest terms first
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(W6L_THREADS) void w6_lin_kernel(const WsArgs a) {
     for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSRC; ++s, ++q) {
-      w6_mma4(acc, wh[s], wm[s], wl[s], smem6 + (q & 1) * W6L_BUF, ad);
+      w6_mma4<NSRC == 1>(acc, wh[s], wm[s], wl[s], smem6 + (q & 1) * W6L_BUF, ad);
       if (s == NSRC - 1)
         ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
                      J.accumulate != 0);
@@ -192,7 +205,7 @@ static int w6_lin_launch(const WsArgs& a, hipStream_t st) {
 
 bool w6_lin_ok(const WsArgs& a, int nsrc) {
   if (a.njobs < 1 || a.njobs > WS_MAX_JOBS || a.P <= 0 || a.P % 4 != 0 || a.B <= 0 || (long)WS_H * a.P >= (1L << 31) || a.side || a.aff || a.stat ||
-      a.inl_w || (a.maskp && !ws_al16(a.maskp)) || (nsrc != 1 && nsrc != 2))
+      a.inl_w || (a.maskp && !ws_al16(a.maskp)) || nsrc != 1)   // two sources: 96 weight registers, 45+ spills at 128: not offered
     return false;
   for (int i = 0; i < a.njobs; ++i) {
     const WsJob& j = a.job[i];
@@ -204,8 +217,7 @@ bool w6_lin_ok(const WsArgs& a, int nsrc) {
 
 int w6_lin_run(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   if (!w6_lin_ok(a, nsrc)) return fail(DPPM_E_INVALID, "w6_lin: unsupported arguments");
-  if (nsrc == 1) return trans ? w6_lin_launch<1, true>(a, st) : w6_lin_launch<1, false>(a, st);
-  return trans ? w6_lin_launch<2, true>(a, st) : w6_lin_launch<2, false>(a, st);
+  return trans ? w6_lin_launch<1, true>(a, st) : w6_lin_launch<1, false>(a, st);
 }
 
 }  // namespace dppm
