@@ -176,16 +176,28 @@ __global__ __launch_bounds__(W6L_THREADS) void w6_lin_kernel(const WsArgs a) {
 #pragma unroll
     for (int s = 0; s < NSRC; ++s, ++q) {
       w6_mma4<NSRC == 1>(acc, wh[s], wm[s], wl[s], smem6 + (q & 1) * W6L_BUF, ad);
-      if (s == NSRC - 1)
+      if (s == NSRC - 1) {
+        if (J.Hsaved) {   // backward of an activation: the result times LeakyReLU'(saved activation) (uniform branch)
+          const float* Ht = J.Hsaved + (size_t)b * J.hs_bs + p0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((int)m0 + 16 * j < P - p0) {
+              const float4 h = *reinterpret_cast<const float4*>(Ht + r0 + 16 * j);
+              acc[j][0] *= h.x > 0.f ? 1.f : kSlope; acc[j][1] *= h.y > 0.f ? 1.f : kSlope;
+              acc[j][2] *= h.z > 0.f ? 1.f : kSlope; acc[j][3] *= h.w > 0.f ? 1.f : kSlope;
+            }
+          }
+        }
         ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
                      J.accumulate != 0);
+      }
       __syncthreads();
     }
   }
 }
 
 template <int NSRC, bool TRANS>
-static int w6_lin_launch(const WsArgs& a, hipStream_t st) {
+static int w6_lin_launch(const WsArgs& a, int prof_class, hipStream_t st) {
   static bool set = false;
   const size_t lds = (size_t)2 * W6L_BUF;
   auto kern = w6_lin_kernel<NSRC, TRANS>;
@@ -199,7 +211,7 @@ static int w6_lin_launch(const WsArgs& a, hipStream_t st) {
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W6L_THREADS), lds, st, a);
-  if (prof) prof_after(st, NSRC == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * NSRC * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, NSRC, false, false));
+  if (prof) prof_after(st, prof_class, 2.0 * NSRC * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, NSRC, false, a.job[0].Hsaved != nullptr));
   return check_launch("w6_lin");
 }
 
@@ -210,14 +222,16 @@ bool w6_lin_ok(const WsArgs& a, int nsrc) {
   for (int i = 0; i < a.njobs; ++i) {
     const WsJob& j = a.job[i];
     if (!j.X || !j.W1 || !j.Y || !ws_al16(j.X) || !ws_al16(j.Y) || j.x_bs % 4 || j.y_bs % 4) return false;
+    if (j.Hsaved && (!ws_al16(j.Hsaved) || j.hs_bs % 4 || a.act || j.b1)) return false;   // the derivative form has no bias / activation of its own
     if (nsrc == 2 && (!j.X2 || !j.W2 || !ws_al16(j.X2) || j.x2_bs % 4)) return false;
   }
   return true;
 }
 
-int w6_lin_run(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
+int w6_lin_run(const WsArgs& a, int nsrc, bool trans, hipStream_t st, int prof_class) {
   if (!w6_lin_ok(a, nsrc)) return fail(DPPM_E_INVALID, "w6_lin: unsupported arguments");
-  return trans ? w6_lin_launch<1, true>(a, st) : w6_lin_launch<1, false>(a, st);
+  if (prof_class < 0) prof_class = PROF_WS_COLS;
+  return trans ? w6_lin_launch<1, true>(a, prof_class, st) : w6_lin_launch<1, false>(a, prof_class, st);
 }
 
 }  // namespace dppm
