@@ -42,27 +42,31 @@ __device__ __forceinline__ void w4_mma4(floatx4 (&acc)[4], const uintx4 (&wh)[4]
 // reads-then-MFMAs is pinned, or the scheduler hoists a tile's worth of reads over the accumulators' registers.
 template <int NS, bool W_IS_A>
 __device__ __forceinline__ void w4_mma8(floatx4 (&acc)[2][4], const uintx4 (&wh)[2][4], const uintx4 (&wl)[2][4], const char* __restrict__ T, const W3Addr& ad) {
-  uintx4 xh = *reinterpret_cast<const uintx4*>(T + w3_off(ad, 0, 0)), xl = xh;
-  if (NS > 1) xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, 0, 0));
+  // Two fragment sets in turn (no copies): while the six MFMAs of step n run from one set, the reads of step n+1 are already in
+  // flight into the other.  sched_barrier(0) keeps that program order: with sched_group_barrier alone the scheduler paired every
+  // read group with the MFMAs that CONSUME it (reads, wait, MFMAs -- the LDS latency in front of every step).
+  uintx4 xh[2], xl[2];
+  xh[0] = *reinterpret_cast<const uintx4*>(T + w3_off(ad, 0, 0));
+  xl[0] = xh[0];
+  if (NS > 1) xl[0] = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, 0, 0));
 #pragma unroll
   for (int n = 0; n < 16; ++n) {
-    const int s = n >> 2, j = n & 3;
-    const uintx4 ch_ = xh, cl_ = xl;
+    const int s = n >> 2, j = n & 3, cur = n & 1, nxt = cur ^ 1;
     if (n + 1 < 16) {
       const unsigned off = w3_off(ad, (n + 1) & 3, (n + 1) >> 2);
-      xh = *reinterpret_cast<const uintx4*>(T + off);
-      if (NS > 1) xl = *reinterpret_cast<const uintx4*>(T + W3_IMG + off);
-      __builtin_amdgcn_sched_group_barrier(0x100, NS > 1 ? 2 : 1, 0);
+      xh[nxt] = *reinterpret_cast<const uintx4*>(T + off);
+      if (NS > 1) xl[nxt] = *reinterpret_cast<const uintx4*>(T + W3_IMG + off); else xl[nxt] = xh[nxt];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       if (NS > 1) {
-        acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], cl_, acc[cb][j]) : w3_mfma(cl_, wh[cb][s], acc[cb][j]);
-        acc[cb][j] = W_IS_A ? w3_mfma(wl[cb][s], ch_, acc[cb][j]) : w3_mfma(ch_, wl[cb][s], acc[cb][j]);
+        acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], xl[cur], acc[cb][j]) : w3_mfma(xl[cur], wh[cb][s], acc[cb][j]);
+        acc[cb][j] = W_IS_A ? w3_mfma(wl[cb][s], xh[cur], acc[cb][j]) : w3_mfma(xh[cur], wl[cb][s], acc[cb][j]);
       }
-      acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], ch_, acc[cb][j]) : w3_mfma(ch_, wh[cb][s], acc[cb][j]);
+      acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], xh[cur], acc[cb][j]) : w3_mfma(xh[cur], wh[cb][s], acc[cb][j]);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NS > 1 ? 6 : 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -220,21 +224,31 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
 }
 
 // Fused MLP  out = (W2 LeakyReLU(W1 norm(X) + b1) + b2) * mask  (model/ppgn.py:58-59), one job (m1 or m2) per workgroup.
-// Stagers (waves 0-7): X tiles (NRM: through the source's instance norm, a.aff) and the tile's mask row.  Per barrier interval
-// waves 8-11 start tile i (first product from X[i & 1], bias, LeakyReLU, split into the hidden image H[i & 1]) while waves 12-15
-// finish tile i-1 (second product from H[(i-1) & 1], bias, mask, 16-byte stores): one barrier per tile, X and H double-buffered.
-// Tile i travels in the stagers' register set i % 3.
-template <int NS, bool NRM, bool INLIN>
-__global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
+// Stagers (waves 0 .. STG-1): X tiles (NRM: through the source's instance norm, a.aff) and the tile's mask row.  Per barrier
+// interval the next four waves start tile i (first product from X[i & 1], bias, LeakyReLU, split into the hidden image H[i & 1])
+// while the last four finish tile i-1 (second product from H[(i-1) & 1], bias, mask, 16-byte stores): one barrier per tile, X and
+// H double-buffered.  Tile i travels in the stagers' register set i % 3.
+// STG = 4 (the form launched): 12 waves at 168 registers -- every staging thread carries two channel groups (4 cg .. and
+// 64 + 4 cg ..) and the multipliers have room for a second X fragment set (w4_mma8's reads one step ahead).  STG = 8 would be 16
+// waves at 128 registers, one channel group per staging thread.
+// NRM: the graph's 256-float (scale, shift) table goes through LDS instead of 16 registers per tile in flight: with tile q the
+// stagers request one float4 of the table of tile q+1's graph (pre.t), write it to As[(q+1) & 1] when tile q lands, and read their
+// channels' pairs from As[q' & 1] when tile q' = q+1 lands one barrier later.
+template <int NQ> struct W4PreT;
+template <> struct W4PreT<1> { float4 a, b, c, d, t; float m; };
+template <> struct W4PreT<2> { float4 a, b, c, d, e, f, g, h, t; float m; };
+template <int NS, bool NRM, bool INLIN, int STG>
+__global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem4[];
   constexpr int NIMG = NS > 1 ? 2 : 1;
   constexpr int BUF = NIMG * W3_IMG;
+  constexpr int NQ = 8 / STG;                                // channel groups per staging thread
   char* Xs = smem4;                                          // [2][BUF]
   char* Hs = smem4 + 2 * BUF;                                // [2][BUF]
   float* Ms = reinterpret_cast<float*>(smem4 + 4 * BUF);     // [4][64] mask rows: tile i is written in step i-1 and read in step i+1
+  float* As = Ms + 4 * 64;                                   // [2][256] (scale, shift) tables of the graphs of tiles i, i+1 (NRM)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 3;
   const int g = lane >> 4, ci = lane & 15;
   const WsWho who = ws_who(a.njobs);
   const WsJob& J = a.job[who.jid];
@@ -243,14 +257,15 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   const int nloc = (ntiles - who.rank + who.per_job - 1) / who.per_job;   // tiles rank + i * per_job
   const float* maskp = a.maskp;
 
-  if (role == 0) {
+  if (wave < STG) {
     // ------------------------------------------------------------------------------------------------ stagers
+    using Pre = W4PreT<NQ>;
     const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);
     const int oc = 4 * (tid & 15);
     int qi = 0;
-    W4Inl inl{};
-    if (INLIN) inl = w4_inl_load(a, tid);
-    auto issue = [&](W4Pre& pre) {
+    W4Inl inl{}, inl2{};
+    if (INLIN) { inl = w4_inl_load(a, tid); if (NQ == 2) inl2 = w4_inl_load(a, tid + 256); }
+    auto issue = [&](Pre& pre) {
       const int t = who.rank + (qi < nloc ? qi : nloc - 1) * who.per_job;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
       if (INLIN) {   // the source is u0 = in_lin(A, sigma I): two input planes instead of 128 channels
@@ -258,39 +273,74 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
         pre.a = *reinterpret_cast<const float4*>(It);
         pre.b = *reinterpret_cast<const float4*>(It + (size_t)P);
       } else {
-      const float* Xt = J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);
-      pre.a = *reinterpret_cast<const float4*>(Xt);
-      pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
-      pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
-      pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+        const float* Xt = J.X + (size_t)b * J.x_bs + p0 + ((p0 + oc < P) ? o0 : 0u);
+        pre.a = *reinterpret_cast<const float4*>(Xt);
+        pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
+        pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
+        pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
+        if constexpr (NQ == 2) {
+          const float* Xu = Xt + (size_t)64 * P;
+          pre.e = *reinterpret_cast<const float4*>(Xu);
+          pre.f = *reinterpret_cast<const float4*>(Xu + (size_t)P);
+          pre.g = *reinterpret_cast<const float4*>(Xu + (size_t)2 * P);
+          pre.h = *reinterpret_cast<const float4*>(Xu + (size_t)3 * P);
+        }
       }
       if (NRM) {
-        const float* T = a.aff + (size_t)b * 256 + 4 * (tid >> 4);
-        pre.sc = *reinterpret_cast<const float4*>(T);
-        pre.sh = *reinterpret_cast<const float4*>(T + 128);
+        const int t1 = who.rank + (qi + 1 < nloc ? qi + 1 : nloc - 1) * who.per_job;
+        pre.t = *reinterpret_cast<const float4*>(a.aff + (size_t)__builtin_amdgcn_readfirstlane(t1 / tpp) * 256 + 4 * lane);
       }
       if (maskp) pre.m = maskp[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
       ++qi;
     };
     int li = 0;
-    auto land = [&](const W4Pre& pre) {                      // tile li -> X[li & 1], mask row li & 3
+    auto land = [&](const Pre& pre) {                        // tile li -> X[li & 1], mask row li & 3
       const int t = who.rank + (li < nloc ? li : nloc - 1) * who.per_job;
       const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
       const bool in = li < nloc && p0 + oc < P;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
-      if (INLIN) {
-        const float4 A4 = pre.a, S4 = pre.b;
-        xa = in ? w4_inl_row(inl, 0, A4, S4) : z; xb = in ? w4_inl_row(inl, 1, A4, S4) : z;
-        xc = in ? w4_inl_row(inl, 2, A4, S4) : z; xd = in ? w4_inl_row(inl, 3, A4, S4) : z;
+      char* Xb = Xs + (li & 1) * BUF;
+      const float* Ab = As + (li & 1) * 256 + 4 * (tid >> 4);
+      {
+        float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+        if (INLIN) {
+          const float4 A4 = pre.a, S4 = pre.b;
+          xa = in ? w4_inl_row(inl, 0, A4, S4) : z; xb = in ? w4_inl_row(inl, 1, A4, S4) : z;
+          xc = in ? w4_inl_row(inl, 2, A4, S4) : z; xd = in ? w4_inl_row(inl, 3, A4, S4) : z;
+        }
+        if (NRM) {
+          const float4 sc = *reinterpret_cast<const float4*>(Ab), sh = *reinterpret_cast<const float4*>(Ab + 128);
+          w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
+        }
+        w3_tile_store4<NS>(xa, xb, xc, xd, Xb, tid);
       }
-      if (NRM) { w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w); }
-      w3_tile_store4<NS>(xa, xb, xc, xd, Xs + (li & 1) * BUF, tid);
-      if (tid < 64) Ms[(li & 3) * 64 + tid] = (maskp && li < nloc && p0 + lane < P) ? pre.m : (maskp ? 0.f : 1.f);
+      if constexpr (NQ == 2) {                               // channels 64 + 4 cg ..: the image slots of "thread tid + 256"
+        float4 xa, xb, xc, xd;
+        if (INLIN) {
+          const float4 A4 = pre.a, S4 = pre.b;
+          xa = in ? w4_inl_row(inl2, 0, A4, S4) : z; xb = in ? w4_inl_row(inl2, 1, A4, S4) : z;
+          xc = in ? w4_inl_row(inl2, 2, A4, S4) : z; xd = in ? w4_inl_row(inl2, 3, A4, S4) : z;
+        } else {
+          xa = in ? pre.e : z; xb = in ? pre.f : z; xc = in ? pre.g : z; xd = in ? pre.h : z;
+        }
+        if (NRM) {
+          const float4 sc = *reinterpret_cast<const float4*>(Ab + 64), sh = *reinterpret_cast<const float4*>(Ab + 192);
+          w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
+        }
+        w3_tile_store4<NS>(xa, xb, xc, xd, Xb, tid + 256);
+      }
+      if (tid < 64) {
+        Ms[(li & 3) * 64 + tid] = (maskp && li < nloc && p0 + lane < P) ? pre.m : (maskp ? 0.f : 1.f);
+        if (NRM) *reinterpret_cast<float4*>(As + ((li + 1) & 1) * 256 + 4 * tid) = pre.t;
+      }
       ++li;
     };
-    W4Pre p0s, p1s, p2s;
+    Pre p0s, p1s, p2s;
     p0s.m = p1s.m = p2s.m = 1.f;
+    if (NRM) {                                               // tile 0's table, directly
+      if (tid < 64) *reinterpret_cast<float4*>(As + 4 * tid) = *reinterpret_cast<const float4*>(a.aff + (size_t)(who.rank / tpp) * 256 + 4 * tid);
+      __syncthreads();
+    }
     issue(p0s); issue(p1s); issue(p2s);
     land(p0s);
     __syncthreads();                                         // tile 0 is in X[0]
@@ -310,15 +360,16 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   }
 
   // -------------------------------------------------------------------------------------------------- multipliers
-  // Waves 8-11 take the first product, waves 12-15 the second; each owns 32 channels (two 16-channel blocks), so that one X
+  // The first four take the first product, the last four the second; each owns 32 channels (two 16-channel blocks), so that one X
   // fragment read from LDS feeds six MFMAs instead of three: with 16 channels per wave the matrix pipe (45 % busy) and the LDS
   // (47 %) took turns inside every wave (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES / SQ_LDS_IDX_ACTIVE of w3_mlp_kernel).
-  const int second = (wave >> 2) & 1, pw = wave & 3;         // product, channel group 32 pw ..
+  const int second = ((wave - STG) >> 2) & 1, pw = (wave - STG) & 3;   // product, channel group 32 pw ..
   uintx4 wh[2][4], wl[2][4];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
     w3_load_w<NS, false>(wh[cb], wl[cb], second ? J.W2 : J.W1, second ? J.ldw2 : J.ldw1, 32 * pw + 16 * cb + ci, g);
   const W3Addr ad = w3_addr(ci, g);
+  if (NRM) __syncthreads();                                  // (the stagers' table of tile 0)
   __syncthreads();                                           // tile 0 is in X[0]
   if (!second) {
     // first product, D = W1 X: the lane holds channels 32 pw + 16 cb + 4 g + r of position 16 j + ci -> hidden image
@@ -387,13 +438,13 @@ __global__ __launch_bounds__(W4_THREADS) void w4_mlp_kernel(const WsArgs a) {
   }
 }
 
-template <int NS>
+template <int NS, int STG>
 static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
   static bool set[3] = {false, false, false};
-  const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + 4 * 64 * sizeof(float);
+  const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + (4 * 64 + 2 * 256) * sizeof(float);
   const bool nrm = a.aff != nullptr, inl = a.inl_w != nullptr;   // in_lin's output is not normalised: never both
   const int which = inl ? 2 : (nrm ? 1 : 0);
-  auto kern = inl ? w4_mlp_kernel<NS, false, true> : (nrm ? w4_mlp_kernel<NS, true, false> : w4_mlp_kernel<NS, false, false>);
+  auto kern = inl ? w4_mlp_kernel<NS, false, true, STG> : (nrm ? w4_mlp_kernel<NS, true, false, STG> : w4_mlp_kernel<NS, false, false, STG>);
   if (!set[which]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(DPPM_E_LAUNCH, "w4_mlp: cannot raise the dynamic LDS limit to %zu bytes", lds);
@@ -403,7 +454,7 @@ static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
   const long slots = w3_slots(a.njobs, ntiles);              // one workgroup per CU: 32 per XCD, jobs that share X on one XCD
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W4_THREADS), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(64 * (STG + 8)), lds, st, a);
   if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
   return check_launch("w4_mlp");
 }
@@ -420,7 +471,9 @@ bool w4_mlp_ok(const WsArgs& a) {
 
 int w4_mlp_run(const WsArgs& a, int ns, hipStream_t st) {
   if (!w4_mlp_ok(a)) return fail(DPPM_E_INVALID, "w4_mlp: unsupported arguments");
-  return ns == 3 ? w4_mlp_launch<3>(a, st) : w4_mlp_launch<1>(a, st);
+  // STG = 4 only: at 16 waves (STG = 8, 128 registers) the second fragment set of w4_mma8 spills inside the multiply loop
+  // (0.72 ms against 0.57 ms per pair at N = 200, B = 32)
+  return ns == 3 ? w4_mlp_launch<3, 4>(a, st) : w4_mlp_launch<1, 4>(a, st);
 }
 
 template <int NS>
