@@ -863,13 +863,12 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
       j.X = x; j.x_bs = x_bs; j.W1 = w0[k]; j.W2 = w1[k]; j.ldw1 = H; j.ldw2 = H; j.b1 = b0[k]; j.b2 = b1[k];
       j.Mid = save_hid ? hid[k] : nullptr; j.mid_bs = hs; j.Y = out[k]; j.y_bs = hs;
     }
-    // split inference modes.  The two organisations run at the same speed at N = 200 (0.58 ms: both are bound by what one CU moves,
-    // X being fetched by the m1 and the m2 workgroup); the form of dppm_wsplit.h is the default, the role-split one (dppm_w4.hip) takes
-    // over where the fused instance norm needs it (per-graph tables that do not fit the former's LDS) or with DPPM_W4MLP=1.
+    // split inference modes: the role-split form (dppm_w4.hip; 0.54 ms per pair at N = 200, B = 32) unless DPPM_W3MLP=1 asks for the
+    // two-group form of dppm_wsplit.h (0.57 ms), which cannot take the in_lin source and needs per-graph norm tables that fit its LDS
     if (!save_hid && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_mlp_ok(wa)) {
       const int tpp = (c.P + WS_TP - 1) / WS_TP;
       const bool tables_fit = w3_contig_ok((long)c.B * tpp, tpp, (int)(8 * w3_slots(2, (long)c.B * tpp)));
-      if ((aff && !tables_fit) || inl || getenv("DPPM_W4MLP") != nullptr) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
+      if ((aff && !tables_fit) || inl || getenv("DPPM_W3MLP") == nullptr) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
     }
     if (inl) return fail(DPPM_E_INVALID, "mlp_pair: the in_lin form needs the role-split kernel");
     // (Training forward: the fused exact-f32 pair below stays.  Two launches of the three-piece-split Linear would run at the HBM

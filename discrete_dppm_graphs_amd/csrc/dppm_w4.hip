@@ -12,6 +12,18 @@
 namespace dppm {
 
 constexpr int W4_THREADS = 1024;
+// Timing instrument, compiled in with -DW4_TRACE_ON=1 only: with DPPM_DBG_W4=2048 workgroup 8 of w4_mlp_kernel records, per barrier
+// interval, the 100 MHz wall clock at which one wave of each role (0 stager, 1 first product, 2 second product) leaves the barrier
+// (k = 0), reaches the next one (k = 1) and ends its MFMA loop (k = 2); the 21st launch writes gpurun_out/w4_trace.txt.
+#ifndef W4_TRACE_ON
+#define W4_TRACE_ON 0
+#endif
+#if W4_TRACE_ON
+__device__ unsigned long long g_w4_trace[3 * 3 * 256];
+#define W4_TRACE(role, i, k) do { if ((a.dbg & 2048) && blockIdx.x == 8 && (i) < 256 && (tid & 63) == 0) g_w4_trace[((i) * 3 + (role)) * 3 + (k)] = wall_clock64(); } while (0)
+#else
+#define W4_TRACE(role, i, k) do { } while (0)
+#endif
 
 struct W4Pre { float4 a, b, c, d, sc, sh; float m; };   // one tile in flight per staging thread (named members: registers)
 
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
       if (g == 0) *reinterpret_cast<float2*>(a.stat + ((size_t)t * WS_H + ch) * 2) = make_float2(piv + dm, fmaxf(s2 - s1 * dm, 0.f));
       if (w8 == 0 && lane == 0) a.cnt[t] = n;
     }
-    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, nullptr, m0, P - p0, bv, false, false);
+    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, nullptr, m0, P - p0, bv, false, false);   // (wide stores, ws_store_wide / _lds: 0.41 - 0.42 ms against 0.40 ms)
     __syncthreads();
   }
 }
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   char* Hs = smem4 + 2 * BUF;                                // [2][BUF]
   float* Ms = reinterpret_cast<float*>(smem4 + 4 * BUF);     // [4][64] mask rows: tile i is written in step i-1 and read in step i+1
   float* As = Ms + 4 * 64;                                   // [2][256] (scale, shift) tables of the graphs of tiles i, i+1 (NRM)
+  float* Rs = As + 2 * 256;                                  // [4][16][WS_WIDE_PITCH] the second product's waves: result blocks on their way out
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, ci = lane & 15;
@@ -349,9 +362,11 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (q + u <= nloc) {
+          if (wave == 0) W4_TRACE(0, q + u, 0);
           if (u == 0) { issue(p0s); land(p1s); }
           else if (u == 1) { issue(p1s); land(p2s); }
           else { issue(p2s); land(p0s); }
+          if (wave == 0) W4_TRACE(0, q + u, 1);
           __syncthreads();
         }
       }
@@ -374,7 +389,14 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   if (!second) {
     // first product, D = W1 X: the lane holds channels 32 pw + 16 cb + 4 g + r of position 16 j + ci -> hidden image
     const unsigned hbase = ci * 256 + (g & 1) * 8;
+    float4 b1w[2];                                           // loaded once: inside the loop every tile would wait for a global load
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float* bp = J.b1 + 32 * pw + 16 * cb + 4 * g;
+      b1w[cb] = J.b1 ? make_float4(bp[0], bp[1], bp[2], bp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int i = 0; i <= nloc; ++i) {
+      if (pw == 0) W4_TRACE(1, i, 0);
       if (i < nloc) {
         char* Hb = Hs + (i & 1) * BUF;
         floatx4 acc[2][4];
@@ -383,9 +405,10 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
         w4_mma8<NS, true>(acc, wh, wl, Xs + (i & 1) * BUF, ad);
+        if (pw == 0) W4_TRACE(1, i, 2);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const float4 b1 = J.b1 ? *reinterpret_cast<const float4*>(J.b1 + 32 * pw + 16 * cb + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 b1 = b1w[cb];
           const unsigned hchunk = (unsigned)(2 * (2 * pw + cb) + (g >> 1)) ^ (unsigned)ci;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -398,19 +421,26 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
           }
         }
       }
+      if (pw == 0) W4_TRACE(1, i, 1);
       __syncthreads();
     }
     return;
   }
-  // second product, D = H^T W2^T: the lane holds positions 16 j + 4 g + r of channel 32 pw + 16 cb + ci -> bias, mask, 16-byte stores
-  // (Skewing this group against the first product's waves on the same SIMDs -- the stores of tile i-2 at the START of interval i,
-  // accumulators kept over the barrier, so that one wave's matrix phase lies beside the other's vector phase -- was slower:
-  // 0.624 ms against 0.590 ms per pair.)
+  // second product, D = H^T W2^T: the lane holds positions 16 j + 4 g + r of channel 32 pw + 16 cb + ci -> bias, through the wave's
+  // LDS patch into 256-byte row pieces, mask, 16-byte stores (ws_store_wide_lds: 0.573 -> 0.538 ms per pair against the result
+  // layout's 64-byte pieces; the DPP form of the transposition 0.546 ms).
+  // W4_TRACE_ON timeline of one 3.2 us interval (N = 200, B = 32, shader clock 1.88 GHz): first product MFMAs until 1.4 us, hidden
+  // image written by 2.7 us; second product MFMAs until 2.1 us (both groups' 192 MFMAs per SIMD are 1.6 us of pipe time), stores out
+  // by 3.0 us; stagers done at 2.6 us.  The groups wait for each other's vector and LDS instructions more than for the matrix pipe.
+  // Skewing this group against the first product's waves on the same SIMDs -- the stores of tile i-2 at the START of interval i,
+  // accumulators kept over the barrier -- was slower (0.56 against 0.535 ms: that epilogue then takes 2.1 us beside the other
+  // group's MFMAs); s_setprio for either role changed nothing.
   float b2v[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) b2v[cb] = J.b2 ? J.b2[32 * pw + 16 * cb + ci] : 0.f;
-  const unsigned m0 = 4 * g;
+  float* Rw = Rs + pw * 16 * WS_WIDE_PITCH;
   for (int i = 0; i <= nloc; ++i) {
+    if (pw == 0) W4_TRACE(2, i, 0);
     if (i >= 1) {                                            // finish tile i-1
       const int t = who.rank + (i - 1) * who.per_job;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
@@ -420,23 +450,13 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
       w4_mma8<NS, false>(acc, wh, wl, Hs + ((i - 1) & 1) * BUF, ad);
+      if (pw == 0) W4_TRACE(2, i, 2);
       const float* Mb = Ms + ((i - 1) & 3) * 64;
       float* Yt = J.Y + (size_t)b * J.y_bs + p0;
-      const int lim = P - p0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pj = (int)m0 + 16 * j;
-        if (pj < lim) {
-          const float4 m = *reinterpret_cast<const float4*>(Mb + pj);
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            float4 v = ws_f4(acc[cb][j]);
-            v.x = (v.x + b2v[cb]) * m.x; v.y = (v.y + b2v[cb]) * m.y; v.z = (v.z + b2v[cb]) * m.z; v.w = (v.w + b2v[cb]) * m.w;
-            *reinterpret_cast<float4*>(Yt + (size_t)(32 * pw + 16 * cb + ci) * P + pj) = v;
-          }
-        }
-      }
+      for (int cb = 0; cb < 2; ++cb) ws_store_wide_lds(acc[cb], Rw, Yt, 32 * pw + 16 * cb, P, b2v[cb], Mb, P - p0, lane);
     }
+    if (pw == 0) W4_TRACE(2, i, 1);
     __syncthreads();
   }
 }
@@ -444,7 +464,7 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
 template <int NS, int STG>
 static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
   static bool set[3] = {false, false, false};
-  const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + (4 * 64 + 2 * 256) * sizeof(float);
+  const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + (4 * 64 + 2 * 256 + 4 * 16 * WS_WIDE_PITCH) * sizeof(float);
   const bool nrm = a.aff != nullptr, inl = a.inl_w != nullptr;   // in_lin's output is not normalised: never both
   const int which = inl ? 2 : (nrm ? 1 : 0);
   auto kern = inl ? w4_mlp_kernel<NS, false, true, STG> : (nrm ? w4_mlp_kernel<NS, true, false, STG> : w4_mlp_kernel<NS, false, false, STG>);
@@ -459,6 +479,18 @@ static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(64 * (STG + 8)), lds, st, a);
   if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
+#if W4_TRACE_ON
+  if (a.dbg & 2048) {
+    static int dumps = 0;
+    if (dumps++ == 20) {                                     // one warm launch
+      static unsigned long long h[3 * 3 * 256];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w4_trace), sizeof(h));
+      FILE* f = fopen("gpurun_out/w4_trace.txt", "w");
+      if (f) { for (int i = 0; i < 256; ++i) fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, h[i * 9], h[i * 9 + 1], h[i * 9 + 2], h[i * 9 + 3], h[i * 9 + 4], h[i * 9 + 5], h[i * 9 + 6], h[i * 9 + 7], h[i * 9 + 8]); fclose(f); }
+    }
+  }
+#endif
   return check_launch("w4_mlp");
 }
 
@@ -472,7 +504,11 @@ bool w4_mlp_ok(const WsArgs& a) {
   return true;
 }
 
-int w4_mlp_run(const WsArgs& a, int ns, hipStream_t st) {
+int w4_mlp_run(const WsArgs& a0, int ns, hipStream_t st) {
+  WsArgs a = a0;
+#if W4_TRACE_ON
+  { const char* e = getenv("DPPM_DBG_W4"); if (e) a.dbg |= atoi(e); }
+#endif
   if (!w4_mlp_ok(a)) return fail(DPPM_E_INVALID, "w4_mlp: unsupported arguments");
   // STG = 4 only: at 16 waves (STG = 8, 128 registers) the second fragment set of w4_mma8 spills inside the multiply loop
   // (0.72 ms against 0.57 ms per pair at N = 200, B = 32)

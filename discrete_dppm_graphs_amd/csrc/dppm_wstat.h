@@ -136,7 +136,7 @@ __device__ __forceinline__ WsWho ws_who(int njobs) {
   return w;
 }
 
-__device__ __forceinline__ float ws_leaky(float v) { return v > 0.f ? v : kSlope * v; }
+__device__ __forceinline__ float ws_leaky(float v) { return fmaxf(v, kSlope * v); }   // = v > 0 ? v : slope v for 0 < slope < 1, one instruction less
 __device__ __forceinline__ float4 ws_f4(const floatx4& a) { return make_float4(a[0], a[1], a[2], a[3]); }
 
 // result tile -> global: optional LeakyReLU, mask, accumulate.  Yt / Mt: uniform pointers to the tile's first position;
@@ -159,6 +159,87 @@ __device__ __forceinline__ void ws_store_out(const floatx4 (&acc)[4], float* __r
       }
       *reinterpret_cast<float4*>(Yt + r0 + 16 * j) = v;
     }
+  }
+}
+
+// The same with WIDE stores.  In the MFMA result layout a wave's store instruction covers 16 channel rows x 64 bytes: half a
+// 128-byte line per row and instruction, and the L2 sees every line twice (tools/dbg/cubw.hip: the MLP pair's traffic shape takes
+// 0.49 ms with such stores against 0.39 ms with 256-byte row pieces).  A 4 x 4 transpose inside every quad of lanes (ci & 3) x
+// (position groups j), two quad_perm DPP exchanges per register, turns the lane's data into: register k = channel 4 (ci >> 2) + k,
+// positions 16 (ci & 3) + 4 g ..: an instruction then covers 4 rows x 256 contiguous bytes.
+__device__ __forceinline__ float ws_dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float ws_dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ void ws_quad_transpose(floatx4 (&a)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {                         // lanes ci ^ 1 trade registers (p, p + 1)
+      const float x = a[p][c], y = a[p + 1][c];
+      const float recv = ws_dpp_xor1(b0 ? x : y);
+      a[p][c] = b0 ? recv : x; a[p + 1][c] = b0 ? y : recv;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {                            // lanes ci ^ 2 trade registers (p, p + 2)
+      const float x = a[p][c], y = a[p + 2][c];
+      const float recv = ws_dpp_xor2(b1 ? x : y);
+      a[p][c] = b1 ? recv : x; a[p + 2][c] = b1 ? y : recv;
+    }
+  }
+}
+// acc (destroyed): the lane's 16 results, channel ch0 + ci, positions 16 j + 4 g + r.  Yt: uniform pointer to the tile's first
+// position of channel 0; bvp: null (bias already added) or ws_bias_wide(bias, ch0, lane), loaded once per kernel; Mt: the tile's mask row (LDS or global) or null.
+__device__ __forceinline__ float4 ws_bias_wide(const float* __restrict__ bias, int ch0, int lane) {   // of channels ch0 + (ci & 12) + 0..3
+  if (!bias) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* b = bias + ch0 + (lane & 12);
+  return make_float4(b[0], b[1], b[2], b[3]);
+}
+__device__ __forceinline__ void ws_store_wide(floatx4 (&acc)[4], float* __restrict__ Yt, int ch0, int P, const float4* bvp,
+                                              const float* __restrict__ Mt, int lim, int lane, bool act, bool accumulate) {
+  ws_quad_transpose(acc, lane);
+  const int ci = lane & 15, g = lane >> 4, q = ci & 3, c4 = ch0 + (ci & 12);
+  const int pos = 16 * q + 4 * g;
+  if (pos >= lim) return;
+  float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (Mt) m = *reinterpret_cast<const float4*>(Mt + pos);
+  float* Y = Yt + (size_t)c4 * P + pos;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 v = ws_f4(acc[k]);
+    if (bvp) {
+      const float bk = k == 0 ? bvp->x : (k == 1 ? bvp->y : (k == 2 ? bvp->z : bvp->w));
+      v.x += bk; v.y += bk; v.z += bk; v.w += bk;
+    }
+    if (act) { v.x = ws_leaky(v.x); v.y = ws_leaky(v.y); v.z = ws_leaky(v.z); v.w = ws_leaky(v.w); }
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(Y + (size_t)k * P);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(Y + (size_t)k * P) = v;
+  }
+}
+
+// The same transposition through a wave-private LDS patch R (16 rows of WS_WIDE_PITCH floats, 16-byte aligned) instead of the
+// DPP exchanges: 8 LDS instructions in place of ~64 vector instructions per 16 x 64 result block, for kernels whose waves are short
+// of vector issue slots rather than of LDS cycles.  bias: the lane's channel ch0 + ci.  The pitch keeps both the b128 stores (8
+// lanes of one g, rows ci .. ci+7) and the b128 loads (16 lanes along a row) free of bank conflicts.
+constexpr int WS_WIDE_PITCH = 68;
+__device__ __forceinline__ void ws_store_wide_lds(const floatx4 (&acc)[4], float* __restrict__ R, float* __restrict__ Yt, int ch0, int P, float bias,
+                                                  const float* __restrict__ Mt, int lim, int lane) {
+  const int ci = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    *reinterpret_cast<float4*>(R + ci * WS_WIDE_PITCH + 16 * j + 4 * g) = make_float4(acc[j][0] + bias, acc[j][1] + bias, acc[j][2] + bias, acc[j][3] + bias);
+  const int pos = 4 * ci;
+  float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (Mt) m = *reinterpret_cast<const float4*>(Mt + pos);
+  float* Y = Yt + (size_t)(ch0 + g) * P + pos;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 v = *reinterpret_cast<const float4*>(R + (4 * k + g) * WS_WIDE_PITCH + pos);
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    if (pos < lim) *reinterpret_cast<float4*>(Y + (size_t)(4 * k) * P) = v;
   }
 }
 

@@ -413,8 +413,13 @@ def test_mlp_pair_block(ops, H, P, B, save):
 # random-initialised network (logits there are small differences of O(10) activations).
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("P,B", [(64, 1), (1188, 3), (40000, 1)])
-def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B):
+@pytest.mark.parametrize("form", ["role_split", "two_group"])   # dppm_w4.hip (default) / dppm_wsplit.h (DPPM_W3MLP=1)
+def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B, form, monkeypatch):
     H = 128
+    if form == "two_group":
+        monkeypatch.setenv("DPPM_W3MLP", "1")
+    else:
+        monkeypatch.delenv("DPPM_W3MLP", raising=False)
     rng = np.random.default_rng(P)
     X = rng.normal(size=(B, H, P)).astype(np.float32)
     maskp = (rng.random((B, P)) < 0.8).astype(np.float32)
@@ -611,13 +616,19 @@ def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
     sigma = rng.uniform(0, 0.5, size=B)
     W = op.init_weights(L, H, seed=N + 3 * L)
     got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    os.environ["DPPM_W3MLP"] = "1"                           # the two-group MLP where its tables fit (the role-split one elsewhere)
+    try:
+        got3, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+    finally:
+        del os.environ["DPPM_W3MLP"]
     os.environ["DPPM_DISABLE_NORMFUSE"] = "1"
     try:
         plain, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
     finally:
         del os.environ["DPPM_DISABLE_NORMFUSE"]
-    assert np.isfinite(got).all()
+    assert np.isfinite(got).all() and np.isfinite(got3).all()
     close(got, plain, tol=tol)
+    close(got3, plain, tol=tol)
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)

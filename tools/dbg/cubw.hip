@@ -47,6 +47,74 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const float4* __restric
   if (!(mode & 2) && acc.x + acc.y + acc.z + acc.w == 123.456f) sink[wg] = acc.x;   // keeps the loads alive
 }
 
+// The MLP pair's access shape: X [B][128][P] read in tiles of 64 positions x 128 channel rows (256-byte row pieces, row stride
+// 4 P bytes), by the workgroups of job 0 and job 1 (neighbours on one XCD take the same tile); each job writes its own Y in the
+// same shape.  Thread mapping of the staging waves: rows 4 (tid >> 4) .. + 3, float4 column tid & 15; three tiles in flight.
+// narrow: stores in the multipliers' mapping instead (a wave's store covers 16 rows x 64 bytes).
+__global__ __launch_bounds__(THREADS) void tile_kernel(const float* __restrict__ X, float* __restrict__ Y0, float* __restrict__ Y1, int P, int B,
+                                                       int mode, int njobs, int narrow, float* __restrict__ sink) {
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int xcd = wg & 7, slot = wg >> 3;
+  const int job = njobs == 2 ? (slot & 1) : 0;
+  const int rank = njobs == 2 ? xcd + 8 * (slot >> 1) : wg, per_job = 256 / njobs;
+  const int tpp = P / 64, ntiles = B * tpp;
+  float* Y = job ? Y1 : Y0;
+  const size_t ro = (size_t)(4 * (tid >> 4)) * P + 4 * (tid & 15);
+  const int lane = tid & 63, wave = tid >> 6;
+  const size_t no = (size_t)(16 * wave + (lane & 15)) * P + 4 * (lane >> 4);   // narrow: row 16 wave + ci, positions 4 g + 16 j
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = rank; i < ntiles; i += 3 * per_job) {
+    float4 v[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = i + u * per_job < ntiles ? i + u * per_job : i;
+      const int b = t / tpp, p0 = (t - b * tpp) * 64;
+      const float* Xt = X + (size_t)b * 128 * P + p0 + ro;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (mode & 1) v[u][r] = *reinterpret_cast<const float4*>(Xt + (size_t)r * P);
+        else v[u][r] = make_float4((float)t, 1.f, 2.f, 3.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = i + u * per_job;
+      if (t >= ntiles) break;
+      const int b = t / tpp, p0 = (t - b * tpp) * 64;
+      if (mode & 2) {
+        float* Yt = Y + (size_t)b * 128 * P + p0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (narrow) *reinterpret_cast<float4*>(Yt + no + 16 * r) = v[u][r];
+          else *reinterpret_cast<float4*>(Yt + ro + (size_t)r * P) = v[u][r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc.x += v[u][r].x; acc.y += v[u][r].y; acc.z += v[u][r].z; acc.w += v[u][r].w; }
+      }
+    }
+  }
+  if (!(mode & 2) && acc.x + acc.y + acc.z + acc.w == 123.456f) sink[wg] = acc.x;
+}
+
+static void run_tile(const char* name, const float* X, float* Y0, float* Y1, int P, int B, int mode, int njobs, int narrow, float* sink, double units) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(tile_kernel, dim3(256), dim3(THREADS), 0, 0, X, Y0, Y1, P, B, mode, njobs, narrow, sink);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(tile_kernel, dim3(256), dim3(THREADS), 0, 0, X, Y0, Y1, P, B, mode, njobs, narrow, sink);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double unit = (double)B * 128 * P * 4;
+  printf("%-22s %8.3f ms  %4.1f plane-sets of %.0f MB across the CU boundary: %6.2f TB/s\n", name, ms, units, unit / 1e6, units * unit / (ms * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
 static double run(const char* name, const float4* src, float4* dst, size_t n4, size_t wrap, int mode, int share, float* sink, double bytes) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -78,6 +146,19 @@ int main() {
   run("write", a, b, n4, n4, 2, 0, sink, (double)total);
   run("copy", a, b, n4, n4, 3, 0, sink, 2.0 * total);
   run("pair", a, b, n4, n4, 3, 2, sink, 2.0 * total);
+  {
+    const int P = 40000, B = 32;                              // N = 200, 32 graphs: the bench geometry
+    const float* X = reinterpret_cast<const float*>(a);
+    float* Y0 = reinterpret_cast<float*>(b);
+    float* Y1 = Y0 + (size_t)B * 128 * P;                     // 3 x 655 MB < 2 GiB per buffer
+    run_tile("tile read, 1 job", X, Y0, Y1, P, B, 1, 1, 0, sink, 1);
+    run_tile("tile read, 2 jobs", X, Y0, Y1, P, B, 1, 2, 0, sink, 2);
+    run_tile("tile write, 2 jobs", X, Y0, Y1, P, B, 2, 2, 0, sink, 2);
+    run_tile("tile write narrow", X, Y0, Y1, P, B, 2, 2, 1, sink, 2);
+    run_tile("tile mlp shape", X, Y0, Y1, P, B, 3, 2, 0, sink, 4);
+    run_tile("tile mlp shape narrow", X, Y0, Y1, P, B, 3, 2, 1, sink, 4);
+    run_tile("tile copy, 1 job", X, Y0, Y1, P, B, 3, 1, 0, sink, 2);
+  }
   CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(sink));
   return 0;
 }
