@@ -225,14 +225,27 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       {
         const float4 ws0 = *reinterpret_cast<const float4*>(Cs + c4), ws1 = *reinterpret_cast<const float4*>(Cs + WS_H + c4);
         const float4 cb = *reinterpret_cast<const float4*>(Cs + 2 * WS_H + c4);
+        // The side values (and NRM: the mask) of the four position groups are requested together and waited for with an explicit
+        // vmcnt(0).  This wave also reloads spilled registers from scratch in here, and with only the compiler's counted waits
+        // (vmcnt(6), (5), (3), (1) over that mix of scratch and global loads) about one NRM forward in 15 at N = 200, B = 32 came
+        // out with 4-6 logits of ONE position group of ONE odd tile 5e-4 .. 6e-3 off, every workspace region before the logits
+        // being bit-identical (tools/dbg/head_race.py, ws_diff.py): as if a side / mask value had been used before its load had
+        // landed.  Built with -mllvm -amdgpu-waitcnt-forcezero, or with this wait: none in 150 forwards.
+        float av4[4], sv4[4], mk4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                        // R = acc + side input + bias -> registers and hidden image
+        for (int j = 0; j < 4; ++j) {
           const int p = sp0 + WS_TP * t + 16 * j + ci;
           const int pc = p < P ? p : 0;
-          const float av = side[pc], sv = side[(size_t)P + pc];
+          av4[j] = side[pc]; sv4[j] = side[(size_t)P + pc];
+          mk4[j] = NRM ? a.maskp[(size_t)b * P + pc] : 1.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt and lgkmcnt untouched
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                        // R = acc + side input + bias -> registers and hidden image
+          const float av = av4[j], sv = sv4[j];
           floatx4& r = acc[t][j];
           if (NRM) {
-            if (!(a.maskp[(size_t)b * P + pc] > 0.f)) r = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (!(mk4[j] > 0.f)) r = floatx4{0.f, 0.f, 0.f, 0.f};
           }
           r[0] += ws0.x * av + ws1.x * sv + cb.x; r[1] += ws0.y * av + ws1.y * sv + cb.y;
           r[2] += ws0.z * av + ws1.z * sv + cb.z; r[3] += ws0.w * av + ws1.w * sv + cb.w;

@@ -310,7 +310,10 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
     auto land = [&](const Pre& pre) {                        // tile li -> X[li & 1], mask row li & 3
       const int t = who.rank + (li < nloc ? li : nloc - 1) * who.per_job;
       const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
-      const bool in = li < nloc && p0 + oc < P;
+#ifndef EXPERIMENT_IN
+#define EXPERIMENT_IN (li < nloc && p0 + oc < P)
+#endif
+      const bool in = EXPERIMENT_IN;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       char* Xb = Xs + (li & 1) * BUF;
       const float* Ab = As + (li & 1) * 256 + 4 * (tid >> 4);

@@ -632,3 +632,24 @@ def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
+
+
+def test_inference_forward_is_deterministic_n200(ops):
+    """The bf16x3 inference forward has no atomics and no order that depends on timing: 40 forwards of the same batch at the
+    headline geometry (N = 200, B = 32, one layer + read-out) must be bit-identical.  Regression test for a read-out kernel
+    that used a side-input value before its load had landed in about one forward of 15 (head3_kernel<3, true>: counted vmcnt
+    waits over a mix of scratch and global loads; tools/dbg/head_race.py shows where the logits differed)."""
+    from oracle import ppgn as op
+    B, N, L, H = 32, 200, 1, 128
+    rng = np.random.default_rng(1200 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 3 * L)
+    first = None
+    for r in range(40):
+        out, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+        if first is None:
+            first = out
+        else:
+            bad = np.argwhere(out != first)
+            assert len(bad) == 0, f"run {r}: {len(bad)} logits differ from run 0, first at {bad[0].tolist()}"
