@@ -39,13 +39,13 @@ HBM_PEAK_GBS = 8000.0
 
 # kernel classes of dppm_prof_end (include/dppm_hip.h) -> what runs in them, per precision mode
 KERNEL_NAMES = {
-    "wstat_mlp2": {"split": "w3_mlp_kernel (both per-position MLPs of a PPGN layer, model/ppgn.py:58-59; float32 in HBM, operands split into "
+    "wstat_mlp2": {"split": "w4_mlp_kernel (both per-position MLPs of a PPGN layer, model/ppgn.py:58-59; float32 in HBM, operands split into "
                             "bf16 pieces in LDS, v_mfma_f32_16x16x32_bf16; reads X, writes o1 and o2)",
                    "f32": "ws_mlp_kernel (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32, 8*H^2*P*B FLOP per launch)"},
-    "wstat_sum2": {"split": "w3_lin2_kernel (skip-concat Linear m4, model/ppgn.py:66-69; layer_cat_lin two layer outputs at a time, :318,327)",
+    "wstat_sum2": {"split": "w4_lin2_kernel (skip-concat Linear m4, model/ppgn.py:66-69, with the masked statistics of the fused instance norm)",
                    "f32": "ws_lin_kernel<2> (skip-concat Linear m4 and the layer_cat_lin pairs, v_mfma_f32_16x16x4_f32)"},
     "wstat_cols": {"split": "w3_lin_kernel<.,1> (after_conv, model/ppgn.py:331)", "f32": "ws_lin_kernel<1> (after_conv; transposed data-gradient forms)"},
-    "plane_matmul": {"split": "plane3_kernel (per-channel N x N contraction, model/ppgn.py:62; split-bf16 operands on v_mfma_f32_16x16x32_bf16)",
+    "plane_matmul": {"split": "plane4_kernel (per-channel N x N contraction, model/ppgn.py:62; split-bf16 operands on v_mfma_f32_16x16x32_bf16)",
                      "f32": "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)"},
     "inorm": {"split": "inorm_fwd_kernel (masked instance norm, util/model_helper.py:176-191)", "f32": "inorm_fwd_kernel / inorm_bwd_kernel"},
     "linear_gemm": {"split": "gemm_f32_kernel (per-position linears of networks with H != 128)", "f32": "gemm_f32_kernel (per-position linears, H != 128)"},

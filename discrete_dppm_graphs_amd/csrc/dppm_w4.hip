@@ -310,10 +310,11 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
     auto land = [&](const Pre& pre) {                        // tile li -> X[li & 1], mask row li & 3
       const int t = who.rank + (li < nloc ? li : nloc - 1) * who.per_job;
       const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
-#ifndef EXPERIMENT_IN
-#define EXPERIMENT_IN (li < nloc && p0 + oc < P)
-#endif
-      const bool in = EXPERIMENT_IN;
+      // (The zero fill below is not needed for the result -- positions past the plane's end and landings past the last tile are
+      // never stored -- but a build without these selects in the in_lin form produced wrong SECOND tiles of every workgroup, varying
+      // from run to run, also with all waits forced to zero, which the source does not explain; tools/dbg/mlp_diff.py and
+      // tools/dbg/determinism.py are the checks to run after any change to this kernel.)
+      const bool in = li < nloc && p0 + oc < P;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       char* Xb = Xs + (li & 1) * BUF;
       const float* Ab = As + (li & 1) * 256 + 4 * (tid >> 4);
