@@ -1,0 +1,37 @@
+"""debug: layer-0 MLP output o1 of the in_lin-fused path against the unfused path (DPPM_DISABLE_INLINFUSE=1), per tile / channel / position"""
+import os, sys, numpy as np, torch
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from discrete_dppm_graphs_amd import ops
+from oracle import ppgn as op
+from test_gpu_ppgn import rand_case, dev
+B, N, L, H = 5, 64, 1, 128
+rng = np.random.default_rng(1200 + N + 3)
+A, mask = rand_case(rng, B, N)
+sigma = rng.uniform(0, 0.5, size=B)
+W = op.init_weights(L, H, seed=N + 3 * L)
+tensors = {k: dev(v.detach().numpy()) for k, v in W.items()}
+pack = ops.ParamPack(tensors, L, H)
+sig = dev(np.asarray(sigma, np.float32))
+ld = -(-N // 4) * 4; P = N * ld; S = B * H * P; CT = 2 + L * H
+al = lambda n: -(-n // 64) * 64
+off_tmp1 = al(B * P) + al(B) + al(B * CT * P) + 3 * al(S) + al(L * B * H) + al(S)
+def run():
+    ws = ops.ppgn_workspace(B, N, H, L, False, "cuda"); ws.fill_(float("nan"))
+    ops.ppgn_forward(pack, dev(A), dev(mask), sig, ws, training=False, precision="bf16x3")
+    torch.cuda.synchronize()
+    return ws[off_tmp1:off_tmp1 + S].cpu().numpy().reshape(B, H, P)
+got = run()
+os.environ["DPPM_DISABLE_INLINFUSE"] = "1"
+ref = run()
+d = np.abs(got - ref); sc = np.abs(ref[np.isfinite(ref)]).max()
+print("o1 max diff", np.nanmax(d), "scale", sc, "nan in got", np.isnan(got).sum(), "nan in ref", np.isnan(ref).sum())
+bad = np.argwhere(d > 1e-3 * sc)
+print("bad entries", len(bad))
+if len(bad):
+    import collections
+    print("by graph", collections.Counter(bad[:, 0].tolist()))
+    print("by tile-in-graph (first 10)", sorted(collections.Counter((bad[:, 2] // 64).tolist()).items())[:10])
+    print("by channel block of 16", sorted(collections.Counter((bad[:, 1] // 16).tolist()).items()))
+    print("by position-in-tile group of 16", sorted(collections.Counter((bad[:, 2] % 64 // 16).tolist()).items()))
+    b0, c0, p0 = bad[0]; print("example", bad[0], got[b0, c0, p0], ref[b0, c0, p0])
