@@ -438,7 +438,8 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   // by 3.0 us; stagers done at 2.6 us.  The groups wait for each other's vector and LDS instructions more than for the matrix pipe.
   // Skewing this group against the first product's waves on the same SIMDs -- the stores of tile i-2 at the START of interval i,
   // accumulators kept over the barrier -- was slower (0.56 against 0.535 ms: that epilogue then takes 2.1 us beside the other
-  // group's MFMAs); s_setprio for either role changed nothing.
+  // group's MFMAs); s_setprio for either role changed nothing; both channel blocks through the patch behind ONE wait (block 1 written as
+  // soon as block 0's reads are issued, eight stores in a row) was slower too: 0.549 against 0.515 ms.
   float b2v[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) b2v[cb] = J.b2 ? J.b2[32 * pw + 16 * cb + ci] : 0.f;
