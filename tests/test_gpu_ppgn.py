@@ -653,3 +653,24 @@ def test_inference_forward_is_deterministic_n200(ops):
         else:
             bad = np.argwhere(out != first)
             assert len(bad) == 0, f"run {r}: {len(bad)} logits differ from run 0, first at {bad[0].tolist()}"
+
+
+def test_training_gradients_are_deterministic(ops):
+    """Training forward + backward (float32-grade kernels, split-K weight gradients reduced in a fixed order): 12 evaluations of the
+    same batch (B = 8, N = 200, two layers: every workgroup walks several tiles) give bit-identical logits and gradients."""
+    from oracle import ppgn as op
+    B, N, L, H = 8, 200, 2, 128
+    rng = np.random.default_rng(77 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + L)
+    R = rng.normal(size=(B, N, N)).astype(np.float32) * mask
+    first = None
+    for r in range(12):
+        logits, grads = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
+        if first is None:
+            first = (logits, grads)
+            continue
+        assert np.array_equal(logits, first[0]), f"run {r}: logits differ"
+        for k in grads:
+            assert np.array_equal(grads[k], first[1][k]), f"run {r}: gradient of {k} differs"
