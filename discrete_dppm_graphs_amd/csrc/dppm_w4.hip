@@ -94,9 +94,25 @@ __device__ __forceinline__ W4Inl w4_inl_load(const WsArgs& a, int tid) {
   }
   return r;
 }
+// ws_inlin's three roundings as single-lane instructions that the compiler cannot pack.  Left to itself hipcc turns the rows below into
+// v_pk_mul_f32 / v_pk_fma_f32 with operand-half selects (op_sel) applied straight to the destination pairs of the stagers' global
+// loads, and every build of that shape gave, from run to run, wrong values at the odd positions of a thread's quad in tiles after a
+// workgroup's first; every build without those packed forms is bit-exact ("The in_lin stagers": evidence,
+// what was ruled out, the two hardware probes).  -DW4_INLIN_PACKED restores the packed form for that experiment.
+__device__ __forceinline__ float w4_inlin_s(float w0, float w1, float bc, float a, float s) {
+#ifdef W4_INLIN_PACKED
+  return ws_inlin(w0, w1, bc, a, s);
+#else
+  float t;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(w0), "v"(a));
+  asm("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w1), "v"(s));
+  asm("v_add_f32 %0, %0, %1" : "+v"(t) : "v"(bc));
+  return t;
+#endif
+}
 __device__ __forceinline__ float4 w4_inl_row(const W4Inl& k, int v, const float4& A, const float4& S) {
-  return make_float4(ws_inlin(k.w0[v], k.w1[v], k.b[v], A.x, S.x), ws_inlin(k.w0[v], k.w1[v], k.b[v], A.y, S.y),
-                     ws_inlin(k.w0[v], k.w1[v], k.b[v], A.z, S.z), ws_inlin(k.w0[v], k.w1[v], k.b[v], A.w, S.w));
+  return make_float4(w4_inlin_s(k.w0[v], k.w1[v], k.b[v], A.x, S.x), w4_inlin_s(k.w0[v], k.w1[v], k.b[v], A.y, S.y),
+                     w4_inlin_s(k.w0[v], k.w1[v], k.b[v], A.z, S.z), w4_inlin_s(k.w0[v], k.w1[v], k.b[v], A.w, S.w));
 }
 
 // Y = W1 X1 + W2 norm(X2) + b per 64-position tile (model/ppgn.py:66-69: m4 on cat(mm, x)); NRM: X2 is staged through its instance
@@ -310,20 +326,15 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
     auto land = [&](const Pre& pre) {                        // tile li -> X[li & 1], mask row li & 3
       const int t = who.rank + (li < nloc ? li : nloc - 1) * who.per_job;
       const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
-      // (The zero fill below is not needed for the result -- positions past the plane's end and landings past the last tile are
-      // never stored -- but a build without these selects in the in_lin form produced wrong SECOND tiles of every workgroup, varying
-      // from run to run, also with all waits forced to zero, which the source does not explain; tools/dbg/mlp_diff.py and
-      // tools/dbg/determinism.py are the checks to run after any change to this kernel.)
-      const bool in = li < nloc && p0 + oc < P;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      // No zero fill: positions past the plane's end and landings past the last tile hold clamped duplicates that no store uses.
       char* Xb = Xs + (li & 1) * BUF;
       const float* Ab = As + (li & 1) * 256 + 4 * (tid >> 4);
       {
-        float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
+        float4 xa, xb, xc, xd;
         if (INLIN) {
-          const float4 A4 = pre.a, S4 = pre.b;
-          xa = in ? w4_inl_row(inl, 0, A4, S4) : z; xb = in ? w4_inl_row(inl, 1, A4, S4) : z;
-          xc = in ? w4_inl_row(inl, 2, A4, S4) : z; xd = in ? w4_inl_row(inl, 3, A4, S4) : z;
+          xa = w4_inl_row(inl, 0, pre.a, pre.b); xb = w4_inl_row(inl, 1, pre.a, pre.b); xc = w4_inl_row(inl, 2, pre.a, pre.b); xd = w4_inl_row(inl, 3, pre.a, pre.b);
+        } else {
+          xa = pre.a; xb = pre.b; xc = pre.c; xd = pre.d;
         }
         if (NRM) {
           const float4 sc = *reinterpret_cast<const float4*>(Ab), sh = *reinterpret_cast<const float4*>(Ab + 128);
@@ -333,12 +344,10 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
       }
       if constexpr (NQ == 2) {                               // channels 64 + 4 cg ..: the image slots of "thread tid + 256"
         float4 xa, xb, xc, xd;
-        if (INLIN) {
-          const float4 A4 = pre.a, S4 = pre.b;
-          xa = in ? w4_inl_row(inl2, 0, A4, S4) : z; xb = in ? w4_inl_row(inl2, 1, A4, S4) : z;
-          xc = in ? w4_inl_row(inl2, 2, A4, S4) : z; xd = in ? w4_inl_row(inl2, 3, A4, S4) : z;
+        if constexpr (INLIN) {
+          xa = w4_inl_row(inl2, 0, pre.a, pre.b); xb = w4_inl_row(inl2, 1, pre.a, pre.b); xc = w4_inl_row(inl2, 2, pre.a, pre.b); xd = w4_inl_row(inl2, 3, pre.a, pre.b);
         } else {
-          xa = in ? pre.e : z; xb = in ? pre.f : z; xc = in ? pre.g : z; xd = in ? pre.h : z;
+          xa = pre.e; xb = pre.f; xc = pre.g; xd = pre.h;
         }
         if (NRM) {
           const float4 sc = *reinterpret_cast<const float4*>(Ab + 64), sh = *reinterpret_cast<const float4*>(Ab + 192);

@@ -75,7 +75,8 @@ struct WsArgs {
 };
 
 // one in_lin value; the stand-alone kernel and the staging code of the fused forms share this expression
-__device__ __forceinline__ float ws_inlin(float w0, float w1, float bc, float a, float s) { return w0 * a + w1 * s + bc; }
+// (explicit roundings: product, fused multiply-add, sum -- the order every form of it has to share to stay bit-identical)
+__device__ __forceinline__ float ws_inlin(float w0, float w1, float bc, float a, float s) { return __fadd_rn(__fmaf_rn(w1, s, __fmul_rn(w0, a)), bc); }
 
 __device__ __forceinline__ int ws_hoff(int k) { return k * WS_HP + 16 * (k >> 5); }
 

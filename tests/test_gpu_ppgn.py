@@ -596,6 +596,10 @@ def test_inlin_formed_while_staging(ops, precision, tol, B, N, L):
         del os.environ["DPPM_DISABLE_INLINFUSE"]
     assert np.isfinite(got).all()
     close(got, plain, tol=tol)
+    # the effect this form once had (packed in_lin rows, DESIGN.md section 4 "The in_lin stagers") came and went from run to run
+    for _ in range(3):
+        again, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
+        assert np.array_equal(again, got)
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
@@ -632,6 +636,30 @@ def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
+
+
+@pytest.mark.parametrize("B,N,L", [(5, 64, 3), (3, 50, 2), (2, 200, 2), (1, 300, 2), (40, 24, 2)])
+def test_role_split_kernels_after_lds_poison(ops, B, N, L):
+    """The role-split kernels hand tiles between staging and multiplying waves through LDS (dppm_w4.hip: MLP pair and m4 in their
+    in_lin, fused-norm and plain forms; dppm_head.hip: the read-out; dppm_plane4.hip: the contraction, one block per plane at N <= 224,
+    2 x 2 blocks at N = 300).  With every CU's LDS holding NaN bit patterns (as bf16 pairs, then as float32) before the forward, the
+    logits must be bit-identical to the unpoisoned run: a multiplier that read a slot before its stager wrote it, a mask row or a
+    normalisation table of another tile, or a result patch ahead of its writer would turn that into NaN or into different bytes."""
+    import ctypes as C
+    from discrete_dppm_graphs_amd._lib import check, lib
+    from oracle import ppgn as op
+    H = 128
+    rng = np.random.default_rng(4100 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 7 * L)
+    want, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    assert np.isfinite(want).all()
+    for pattern in (0x7FC07FC0, 0x7FC00000, 0x7F807F80):
+        check(lib.dppm_test_fill_lds(pattern, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dppm_test_fill_lds")
+        got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+        assert np.isfinite(got).all(), f"pattern {pattern:#x}: {int((~np.isfinite(got)).sum())} non-finite logits"
+        assert np.array_equal(got, want), f"pattern {pattern:#x}: {int((got != want).sum())} logits differ from the unpoisoned run"
 
 
 def test_inference_forward_is_deterministic_n200(ops):

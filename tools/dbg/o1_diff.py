@@ -18,6 +18,10 @@ al = lambda n: -(-n // 64) * 64
 off_tmp1 = al(B * P) + al(B) + al(B * CT * P) + 3 * al(S) + al(L * B * H) + al(S)
 def run():
     ws = ops.ppgn_workspace(B, N, H, L, False, "cuda"); ws.fill_(float("nan"))
+    if os.environ.get("O1_POISON"):   # every CU's LDS holds NaN bf16 pairs / NaN floats before the forward
+        import ctypes as C
+        from discrete_dppm_graphs_amd import _lib
+        rc = _lib.lib.dppm_test_fill_lds(int(os.environ["O1_POISON"], 0), C.c_void_p(torch.cuda.current_stream().cuda_stream)); assert rc == 0, rc
     ops.ppgn_forward(pack, dev(A), dev(mask), sig, ws, training=False, precision="bf16x3")
     torch.cuda.synchronize()
     return ws[off_tmp1:off_tmp1 + S].cpu().numpy().reshape(B, H, P)
