@@ -37,21 +37,34 @@ F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # idem, dense bf16
 HBM_PEAK_GBS = 8000.0
 
-# kernel classes of dppm_prof_end (include/dppm_hip.h) -> what runs in them, per precision mode
+# kernel classes x arithmetic of dppm_prof_end (include/dppm_hip_debug.h) -> the kernels that run in them
 KERNEL_NAMES = {
-    "wstat_mlp2": {"split": "w4_mlp_kernel (both per-position MLPs of a PPGN layer, model/ppgn.py:58-59; float32 in HBM, operands split into "
-                            "bf16 pieces in LDS, v_mfma_f32_16x16x32_bf16; reads X, writes o1 and o2)",
-                   "f32": "ws_mlp_kernel (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32, 8*H^2*P*B FLOP per launch)"},
-    "wstat_sum2": {"split": "w4_lin2_kernel (skip-concat Linear m4, model/ppgn.py:66-69, with the masked statistics of the fused instance norm)",
-                   "f32": "ws_lin_kernel<2> (skip-concat Linear m4 and the layer_cat_lin pairs, v_mfma_f32_16x16x4_f32)"},
-    "wstat_cols": {"split": "w3_lin_kernel<.,1> (after_conv, model/ppgn.py:331)", "f32": "ws_lin_kernel<1> (after_conv; transposed data-gradient forms)"},
-    "plane_matmul": {"split": "plane4_kernel (per-channel N x N contraction, model/ppgn.py:62; split-bf16 operands on v_mfma_f32_16x16x32_bf16)",
-                     "f32": "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32, model/ppgn.py:62)"},
-    "inorm": {"split": "inorm_fwd_kernel (masked instance norm, util/model_helper.py:176-191)", "f32": "inorm_fwd_kernel / inorm_bwd_kernel"},
-    "linear_gemm": {"split": "gemm_f32_kernel (per-position linears of networks with H != 128)", "f32": "gemm_f32_kernel (per-position linears, H != 128)"},
-    "wgrad_gemm": {"split": "ws6_wgrad_kernel", "f32": "ws6_wgrad_kernel (weight gradients, three-piece bf16 split) / generic split-K GEMM"},
-    "head": {"split": "head3_kernel (layer_cat_lin + after_conv + final_lin in one pass, model/ppgn.py:318-333)", "f32": "-"},
+    ("wstat_mlp2", "bf16x3"): "w4_mlp_kernel<3,...> (both per-position MLPs of a PPGN layer, model/ppgn.py:58-59; float32 in HBM, operands split into two "
+                              "bf16 pieces in LDS, three v_mfma_f32_16x16x32_bf16 per product; reads X, writes o1 and o2)",
+    ("wstat_mlp2", "bf16"): "w4_mlp_kernel<1,...> (the MLP pair with bf16-rounded operands, one MFMA per product)",
+    ("wstat_mlp2", "f32"): "ws_mlp_kernel (both per-position MLPs of a PPGN layer, v_mfma_f32_16x16x4_f32; training: hidden activations saved; "
+                           "backward form: dpre and dX)",
+    ("wstat_sum2", "bf16x3"): "w4_lin2_kernel<3,...> (skip-concat Linear m4, model/ppgn.py:66-69, with the masked statistics of the fused instance norm)",
+    ("wstat_sum2", "bf16"): "w4_lin2_kernel<1,...>",
+    ("wstat_sum2", "f32"): "ws_lin_kernel<2> (skip-concat Linear m4 and the layer_cat_lin pairs, v_mfma_f32_16x16x4_f32)",
+    ("wstat_cols", "bf16x3"): "w3_lin_kernel<3,1> (after_conv, model/ppgn.py:331)",
+    ("wstat_cols", "f32"): "ws_lin_kernel<1> (after_conv; transposed data-gradient forms), exact f32",
+    ("wstat_cols", "f32x6"): "w6_lin_kernel<1,TRANS> (after_conv forward and every transposed data-gradient form: three bf16 pieces per operand, six "
+                             "v_mfma_f32_16x16x32_bf16 per product)",
+    ("wstat_mlp2", "f32x6"): "w6_lin_kernel pair of the MLP backward (dpre = (W2^T dOut) LeakyReLU'(hid), then dX += W1^T dpre), three-piece split",
+    ("plane_matmul", "bf16x3"): "plane4_kernel<NT,3,...> (per-channel N x N contraction, model/ppgn.py:62; two bf16 pieces per operand, three "
+                                "v_mfma_f32_16x16x32_bf16 per product)",
+    ("plane_matmul", "bf16"): "plane4_kernel<NT,1,...>",
+    ("plane_matmul", "f32x6"): "plane4_kernel<NT,6,1,TA,TB> (the contraction and its two gradient forms in training: three bf16 pieces, six products)",
+    ("plane_matmul", "f32"): "plane_mm16_kernel / plane_mm_kernel (per-channel N x N contraction on v_mfma_f32_16x16x4_f32)",
+    ("inorm", "none"): "inorm_fwd_kernel / inorm_bwd_kernel (masked instance norm, util/model_helper.py:176-191)",
+    ("linear_gemm", "f32"): "gemm_f32_kernel / mlp32_*_kernel / lin32t_kernel (per-position linears of networks with H != 128, exact f32 MFMA)",
+    ("wgrad_gemm", "f32x6"): "ws6_wgrad_kernel (128 x 128 weight gradients over all positions, three-piece bf16 split, six products)",
+    ("wgrad_gemm", "f32"): "ws_wgrad_kernel / wgrad32m_kernel / generic split-K GEMM (weight gradients, exact f32 MFMA)",
+    ("head", "bf16x3"): "head3_kernel<3,...> (layer_cat_lin + after_conv + final_lin in one pass, model/ppgn.py:318-333)",
+    ("head", "bf16"): "head3_kernel<1,...>",
 }
+BF16_PRODUCTS = {"bf16x3": 3, "bf16": 1, "f32x6": 6}    # bf16 MFMAs per float32 product
 
 
 def sbm_graphs(rng, B, N, p_intra=0.3, p_inter=0.005):
@@ -165,37 +178,57 @@ def self_launch(n, argv):
 
 
 # --------------------------------------------------------------------------------------------------- roofline objects
-def kernel_table(prof, mode, dt, traffic_json):
-    """Per kernel class: launches, average launch time, share of the timed region and its roofline against the roof that
-    bounds it.  Split-bf16 kernels (and the instance norm in every mode) are HBM-bound: achieved = algorithmic bytes per launch
-    (every distinct operand read once, every result written once, counted by the library per launch) / average launch time,
-    against 8 TB/s; their matrix work is also shown as a fraction of the dense bf16 MFMA peak (3 MFMAs per product in bf16x3, 1
-    in bf16).  Exact-f32 kernels are bound by the f32 MFMA pipe: algorithmic FLOP/s against 157.3 TFLOP/s."""
-    nterm = {"bf16x3": 3, "bf16": 1}.get(mode, 0)
+def kernel_table(prof, dt, traffic_json, mode):
+    """Per (kernel class, arithmetic): launches, average launch time, share of the timed region and a roofline against the roof
+    that bounds THAT arithmetic.  The library tags every timed launch with the arithmetic it ran in, so a class never mixes pipes:
+      - exact-f32 MFMA launches ("f32"): bound = the f32 matrix pipe, algorithmic FLOP/s against 157.3 TFLOP/s;
+      - launches on the bf16 pipe with split operands ("bf16x3", "bf16", "f32x6") and the instance norm ("none"): bound = HBM,
+        algorithmic bytes per launch (every distinct operand read once, every result written once, counted by the library) / average
+        launch time against 8 TB/s; their matrix work is shown beside it as bf16_mfma_frac = (3, 1 or 6 bf16 MFMAs per product) x
+        algorithmic FLOP/s / 2.5 PFLOP/s.  No bf16-pipe work is ever divided by the f32 peak.
+    Keys are "class/arith".  `traffic` (PMC bytes per launch) applies to the classes of the sampling run in `mode`."""
     table = {}
-    for k, c in prof.items():
+    for (k, ar), c in prof.items():
         if c["launches"] == 0:
             continue
         avg_ms = c["ms"] / c["launches"]
-        is_norm = k == "inorm"
-        flops = 0.0 if is_norm else c["work"]
+        flops = 0.0 if ar == "none" else c["work"]
         tfl = flops / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
         gbs = c["bytes"] / (c["ms"] * 1e-3) / 1e9 if c["ms"] > 0 else 0.0
-        hbm_bound = is_norm or (nterm > 0 and k in ("wstat_mlp2", "wstat_sum2", "wstat_cols", "plane_matmul", "head"))
-        e = {"kernel": KERNEL_NAMES.get(k, {}).get("split" if nterm and not is_norm else "f32", k), "launches": c["launches"],
-             "avg_launch_ms": avg_ms, "share_of_step_time": c["ms"] * 1e-3 / dt,
-             "bytes_per_launch": c["bytes"] / c["launches"], "flops_per_launch": flops / c["launches"]}
-        if hbm_bound:
-            e.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
-            if not is_norm:
-                e["f32_equivalent_tflops"] = tfl
-                e["bf16_mfma_frac"] = nterm * tfl / BF16_MFMA_PEAK_TFLOPS
-        else:
+        e = {"kernel": KERNEL_NAMES.get((k, ar), k), "arithmetic": ar, "launches": c["launches"], "avg_launch_ms": avg_ms,
+             "share_of_step_time": c["ms"] * 1e-3 / dt, "bytes_per_launch": c["bytes"] / c["launches"], "flops_per_launch": flops / c["launches"]}
+        if ar == "f32":
             e.update({"bound": "mfma", "achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MFMA_PEAK_TFLOPS,
                       "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
-        e["traffic"] = (traffic_json or {}).get(k)
-        table[k] = e
+        else:
+            e.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+            if ar in BF16_PRODUCTS:
+                e["f32_equivalent_tflops"] = tfl
+                e["bf16_mfma_frac"] = BF16_PRODUCTS[ar] * tfl / BF16_MFMA_PEAK_TFLOPS
+        e["traffic"] = (traffic_json or {}).get(k) if ar in (mode, "none") else None
+        table[f"{k}/{ar}"] = e
     return table
+
+
+def path_object(table, N, H, L, B, levels_timed, dt_level_s, mode):
+    """The whole denoiser level against SURVEY.md section 8(d): HBM bytes the kernels of one level move by the library's own count
+    (in plane-sets S = B*H*N*ld*4 bytes) against the algorithmic bytes of a fully fused path, 4*N^2*(2 + H + 2LH + LH + 1) per graph;
+    and the level's time against the bound of that fused path on the matrix pipe (its intensity is far above the machine balance)."""
+    ld = -(-N // 4) * 4
+    plane_set = 4.0 * B * H * N * ld
+    moved = sum(e["bytes_per_launch"] * e["launches"] for e in table.values()) / max(levels_timed, 1)
+    alg = 4.0 * N * N * (2 + H + L * 2 * H + L * H + 1) * B
+    F = fwd_flops_per_graph(N, H, L) * B
+    if mode in BF16_PRODUCTS:
+        bound_s = BF16_PRODUCTS[mode] * F / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+    else:
+        bound_s = F / (F32_MFMA_PEAK_TFLOPS * 1e12)
+    return {"plane_set_bytes": plane_set, "plane_sets_moved_per_level": moved / plane_set, "bytes_moved_per_level": moved,
+            "algorithmic_bytes_per_level": alg, "moved_over_algorithmic": moved / alg,
+            "level_ms": 1e3 * dt_level_s, "fused_matrix_bound_ms": 1e3 * bound_s, "frac_of_fused_bound": bound_s / dt_level_s,
+            "hbm_bound_ms_at_moved_bytes": 1e3 * moved / (HBM_PEAK_GBS * 1e9),
+            "note": "bytes are the library's per-launch algorithmic counts of the timed kernels (timed classes only: the diffusion kernels' "
+                    "12 N^2 B bytes per level are not in it)"}
 
 
 def dominant(table):
@@ -218,7 +251,7 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--levels", type=int, default=64)
     ap.add_argument("--batch", type=int, default=32, help="graphs per GPU")
-    ap.add_argument("--train-steps", type=int, default=3, help="timed optimizer steps for the training figure (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=None, help="timed optimizer steps for the training figure (default: max(10, --steps); 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-float32 comparison chains")
     ap.add_argument("--no-prof", action="store_true",
@@ -229,6 +262,8 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true",
                     help="rendezvous only (gloo, no GPU call): checks that --gpus N starts N ranks and relays rank 0's line")
     args = ap.parse_args()
+    if args.train_steps is None:
+        args.train_steps = max(10, args.steps)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -280,7 +315,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    empty_prof = {k: {"ms": 0.0, "work": 0.0, "bytes": 0.0, "launches": 0} for k in ops.PROF_CLASSES}
+    empty_prof = {}
 
     def timed_chains(steps, warmup):
         for w in range(warmup):
@@ -307,18 +342,20 @@ def main():
     # ------------------------------------------------------------------ sampling (headline)
     dt, prof, truncated = timed_chains(args.steps, args.warmup)
     graphs_per_s = args.steps * B * world / dt
-    table = kernel_table(prof, args.precision, dt, traffic)
+    table = kernel_table(prof, dt, traffic, args.precision)
+    path = path_object(table, N, H, L, B, args.steps * T, dt / (args.steps * T), args.precision) if table else None
 
     # the same chains with exact-float32 matrix products: same number of steps, its own kernel table
     exact = None
     if args.precision != "f32" and not args.no_exact_f32:
         model.precision = "f32"
         edt, eprof, _ = timed_chains(args.steps, 1)
-        etable = kernel_table(eprof, "f32", edt, None)
+        etable = kernel_table(eprof, edt, None, "f32")
         exact = {"value": args.steps * B * world / edt, "unit": "graphs/s", "ms_per_step": 1e3 * edt / args.steps, "steps": args.steps,
                  "dtype": "f32", "note": "same workload with DPPM_PREC_F32 (v_mfma_f32_16x16x4_f32) in every kernel",
                  "model_tflops": args.steps * B * world / edt * T * fwd_flops_per_graph(N, H, L) / 1e12,
-                 "roofline": dominant(etable), "kernels": etable}
+                 "roofline": dominant(etable), "kernels": etable,
+                 "path": path_object(etable, N, H, L, B, args.steps * T, edt / (args.steps * T), "f32") if etable else None}
         model.precision = args.precision
 
     # ------------------------------------------------------------------ training throughput (second half of the metric)
@@ -340,9 +377,11 @@ def main():
         tprof = ops.prof_end()[0] if not args.no_prof else empty_prof
         tdt = max_over_ranks(tdt)
         F = fwd_flops_per_graph(N, H, L)
-        ttable = kernel_table(tprof, "f32", tdt, None)
+        ttable = kernel_table(tprof, tdt, None, "train")
         train = {"train_steps_per_s": args.train_steps / tdt, "ms_per_train_step": 1e3 * tdt / args.train_steps,
-                 "global_batch": B * world, "loss": float(loss.item()), "dtype": "f32",
+                 "global_batch": B * world, "loss": float(loss.item()), "timed_steps": args.train_steps,
+                 "dtype": "f32 (float32 tensors; forward linears exact-f32 MFMA, contraction / transposed linears / weight gradients f32x6 = three bf16 "
+                          "pieces per operand on the bf16 pipe, float32-grade: DESIGN.md section 2)",
                  "model_tflops": 3 * F * B * world * args.train_steps / tdt / 1e12,
                  "roofline": dominant(ttable), "kernels": ttable}
         model.eval()
@@ -368,6 +407,7 @@ def main():
                        "parallelism": f"graph-sharded x{world}, no collective"},
             "model_tflops": graphs_per_s * T * F / 1e12,
             "roofline": roofline,
+            "path": path,
             "kernels": table,
             "exact_f32": exact,
             "train": train,

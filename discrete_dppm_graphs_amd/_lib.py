@@ -1,4 +1,4 @@
-"""ctypes binding of libdppm_hip.so (the C-ABI of include/dppm_hip.h).
+"""ctypes binding of libdppm_hip.so (the C-ABI of include/dppm_hip.h, plus the measurement / test hooks of include/dppm_hip_debug.h).
 
 The library is built in-tree by `make -C discrete_dppm_graphs_amd/csrc` (or `__graft_entry__.build()`).
 There is NO fallback: if the shared object is missing or a symbol cannot be resolved, importing this module
@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdppm_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # DPPM_PREC_* of include/dppm_hip.h
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "f32x6": 3}
@@ -74,7 +74,9 @@ SIGNATURES = {
                                         C.c_size_t, c_stream]),
     "dppm_test_fill_lds": (C.c_int, [C.c_uint32, c_stream]),
     "dppm_prof_begin": (C.c_int, [C.c_int]),
-    "dppm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
+    "dppm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int, C.c_int]),
+    "dppm_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "dppm_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "dppm_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int, C.c_float, c_stream]),
 }

@@ -318,7 +318,7 @@ inline int launch_gemm(const GemmArgs& a, int batch_z, bool a_kmajor, bool b_kma
     double k = 0;
     for (int i = 0; i < a.nseg; ++i) k += a.seg[i].K;
     const double batch = a.nsplit > 1 ? (double)batch_z / a.nsplit : (double)batch_z;
-    prof_after(st, a.prof_class, 2.0 * a.M * a.N * k * batch);
+    prof_after(st, a.prof_class, AR_F32, 2.0 * a.M * a.N * k * batch);
   }
   return rc;
 }

@@ -289,8 +289,7 @@ static int head3_launch(const HeadArgs& a, const float* after_w, hipStream_t st)
   const bool nrm = a.aff != nullptr;
   if (nrm && !a.maskp) return fail(DPPM_E_INVALID, "head3: the fused instance norm needs the mask planes");
   auto kern = nrm ? head3_kernel<NS, true> : head3_kernel<NS, false>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return fail(DPPM_E_LAUNCH, "head3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "head3"));
   if ((long)(2 + a.L * WS_H) * a.P >= (1L << 31)) return fail(DPPM_E_INVALID, "head3: P=%d too large", a.P);
   hipLaunchKernelGGL(head_wimg_kernel<NS>, dim3(a.L + 1), dim3(512), 0, st, a.cat_w, a.ldw, after_w, a.L, const_cast<uint4*>(a.wimg));
   DPPM_TRY(check_launch("head_wimg"));
@@ -299,7 +298,7 @@ static int head3_launch(const HeadArgs& a, const float* after_w, hipStream_t st)
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(HD_THREADS), lds, st, a);
-  if (prof) prof_after(st, PROF_HEAD, 2.0 * WS_H * ((double)a.L * WS_H + 2 + WS_H + 1) * a.P * a.B,
+  if (prof) prof_after(st, PROF_HEAD, prof_arith_of_pieces(NS), 2.0 * WS_H * ((double)a.L * WS_H + 2 + WS_H + 1) * a.P * a.B,
                        sizeof(float) * ((double)a.L * WS_H + 2) * a.P * a.B + sizeof(float) * (double)a.N * a.N * a.B);
   return check_launch("head3");
 }

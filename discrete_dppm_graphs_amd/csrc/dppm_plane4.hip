@@ -380,17 +380,12 @@ __global__ __launch_bounds__(P4_THREADS) void plane4_kernel(const PlaneArgs p, i
   }
 }
 
-static int p4_dbg() { const char* e = getenv("DPPM_DBG_P4"); return e ? atoi(e) : 0; }   // timing experiments only: results are wrong
+static int p4_dbg() { return sw(SW_DBG_P4); }   // timing experiments only: results are wrong
 
 template <int NT, int NS, int NBLK, bool TA, bool TB>
 static int plane4_launch_nt(const PlaneArgs& a, int batch, hipStream_t st) {
-  static bool attr_set = false;
   const size_t lds = (size_t)2 * 2 * P4Img<NS>::N * P4Cfg<NT>::IMG;   // stages x operands x images
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane4_kernel<NT, NS, NBLK, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "plane4: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    attr_set = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&plane4_kernel<NT, NS, NBLK, TA, TB>), (size_t)(lds), "plane4"));
   // one workgroup per CU; NBLK = 1: planes dealt round-robin; NBLK = 2: groups of four workgroups (see P4Work), all 256 launched
   const int grid = NBLK == 1 ? (batch < P4_CUS ? batch : P4_CUS) : P4_CUS;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(plane4_kernel<NT, NS, NBLK, TA, TB>), dim3(grid), dim3(P4_THREADS), lds, st, a, batch, p4_dbg());
@@ -452,7 +447,7 @@ int plane4_run(const PlaneArgs& a, int batch, int ns, bool ta, bool tb, hipStrea
   int rc;
   if (ns == 6) rc = ta ? plane6_dispatch<true, false>(a, batch, st) : tb ? plane6_dispatch<false, true>(a, batch, st) : plane6_dispatch<false, false>(a, batch, st);
   else rc = ns > 1 ? plane4_dispatch<3>(a, batch, st) : plane4_dispatch<1>(a, batch, st);
-  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
+  if (prof) prof_after(st, PROF_PLANE_MM, prof_arith_of_pieces(ns), 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
   return rc;
 }
 

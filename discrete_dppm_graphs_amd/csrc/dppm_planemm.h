@@ -331,14 +331,8 @@ __global__ __launch_bounds__(1024) void plane_mm16_kernel(const PlaneArgs p) {
 
 template <int NT, int PBK, bool AK, bool BKM>
 inline int plane_mm16_launch_one(const PlaneArgs& a, int batch, hipStream_t st) {
-  static bool attr_set = false;
   const size_t lds = 4 * (size_t)Plane16Cfg<NT, PBK>::PANEL * sizeof(float);
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane_mm16_kernel<NT, PBK, AK, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "plane_mm16: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    attr_set = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&plane_mm16_kernel<NT, PBK, AK, BKM>), (size_t)(lds), "plane_mm16"));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(plane_mm16_kernel<NT, PBK, AK, BKM>), dim3(batch), dim3(1024), lds, st, a);
   return check_launch("plane_mm16");
 }
@@ -365,7 +359,7 @@ inline int plane_mm_launch(const PlaneArgs& a, int batch, bool a_kmajor, bool b_
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   int rc;
-  static const bool strips_only = getenv("DPPM_PLANE_STRIPS_ONLY") != nullptr;   // A/B switch for measurements
+  const bool strips_only = sw(SW_PLANE_STRIPS_ONLY) != 0;   // A/B switch for measurements
   switch (strips_only ? -nt : nt) {
 #define DPPM_PLANE_CASE(NT_) case NT_: case -NT_: rc = plane_mm_launch_nt<NT_>(a, batch, a_kmajor, b_kmajor, st); break;
 #define DPPM_PLANE16_CASE(NT_) case NT_: rc = plane_mm16_launch_nt<NT_>(a, batch, a_kmajor, b_kmajor, st); break; \
@@ -377,7 +371,7 @@ inline int plane_mm_launch(const PlaneArgs& a, int batch, bool a_kmajor, bool b_
 #undef DPPM_PLANE16_CASE
     default: rc = fail(DPPM_E_UNSUPPORTED, "plane_mm: n=%d exceeds the strip kernel's range", a.n);
   }
-  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
+  if (prof) prof_after(st, PROF_PLANE_MM, AR_F32, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
   return rc;
 }
 

@@ -207,13 +207,8 @@ __global__ __launch_bounds__(1024) void plane3_kernel(const PlaneArgs p) {
 
 template <int NT, int NS>
 inline int plane3_launch_nt(const PlaneArgs& a, int batch, int nblk, hipStream_t st) {
-  static bool attr_set = false;
   const size_t lds = (size_t)2 * 2 * (NS > 1 ? 2 : 1) * P3Cfg<NT>::IMG;   // stages x operands x images
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&plane3_kernel<NT, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "plane3: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    attr_set = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&plane3_kernel<NT, NS>), (size_t)(lds), "plane3"));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(plane3_kernel<NT, NS>), dim3(batch, nblk, nblk), dim3(1024), lds, st, a);
   return check_launch("plane3");
 }
@@ -240,7 +235,7 @@ inline int plane3_launch(const PlaneArgs& a, int batch, hipStream_t st) {
     case 16: rc = plane3_launch_nt<16, NS>(a, batch, 1, st); break;
     default: rc = fail(DPPM_E_UNSUPPORTED, "plane3: n=%d outside 129..1024", a.n);
   }
-  if (prof) prof_after(st, PROF_PLANE_MM, 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
+  if (prof) prof_after(st, PROF_PLANE_MM, prof_arith_of_pieces(NS), 2.0 * a.n * a.n * (double)a.n * batch, 3.0 * sizeof(float) * a.n * (double)a.ld * batch);
   return rc;
 }
 

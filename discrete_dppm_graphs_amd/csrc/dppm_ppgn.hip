@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void inlin_kernel(const float* __restrict__ ca
 
 // A/B switch for measurements: DPPM_DISABLE_WSTAT=1 routes the H = 128 linears through the generic GEMM family.
 inline bool use_wstat(int H) {
-  static const bool off = getenv("DPPM_DISABLE_WSTAT") != nullptr;
+  const bool off = sw(SW_DISABLE_WSTAT) != 0;
   return H == WS_H && !off;
 }
 
@@ -788,7 +788,7 @@ inline bool use_wstat(int H) {
 inline int ws_lin_p(const WsArgs& a, int nsrc, bool trans, int prec, hipStream_t st) {
   // training (DPPM_PREC_F32X6): single-source linears on the bf16 pipe with the three-piece split (dppm_w6.hip); the two-source form
   // does not fit (two matrices x three pieces = 96 registers beside accumulators and fragments) and stays exact f32
-  if (prec == DPPM_PREC_F32X6 && nsrc == 1 && getenv("DPPM_DISABLE_W6") == nullptr && w6_lin_ok(a, nsrc)) return w6_lin_run(a, nsrc, trans, st);
+  if (prec == DPPM_PREC_F32X6 && nsrc == 1 && sw(SW_DISABLE_W6) == 0 && w6_lin_ok(a, nsrc)) return w6_lin_run(a, nsrc, trans, st);
   if (prec == DPPM_PREC_BF16X3) return w3_lin<3>(a, nsrc, trans, st);
   if (prec == DPPM_PREC_BF16) return w3_lin<1>(a, nsrc, trans, st);
   return ws_lin(a, nsrc, trans, st);
@@ -814,13 +814,13 @@ int linear(const Ctx& c, int M, const LinArgs& s0, const LinArgs* s1, const floa
 }
 int linear(const Geo& c, int M, const LinArgs& s0, const LinArgs* s1, const float* bias, int act, const float* mulmask,
            const float* dact, long dact_bs, float* Y, long y_bs, bool accumulate) {
-  static const bool l32_off = getenv("DPPM_DISABLE_LIN32") != nullptr;   // A/B switch for measurements
+  const bool l32_off = sw(SW_DISABLE_LIN32) != 0;   // A/B switch for measurements
   if (M == 32 && s0.K == 32 && s0.w_trans && !s1 && !bias && !act && !mulmask && !l32_off) {
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
     hipLaunchKernelGGL(lin32t_kernel, dim3(cdiv((long)c.B * cdiv(c.P, 16), 4)), dim3(256), 0, c.st, s0.W, s0.ldw, s0.X, s0.x_bs, dact, dact_bs,
                        Y, y_bs, c.P, c.B, accumulate ? 1 : 0, (const float*)nullptr, (float*)nullptr, 0L, 0);
-    if (prof) prof_after(c.st, PROF_LINEAR, 2.0 * 32 * 32 * (double)c.P * c.B);
+    if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 2.0 * 32 * 32 * (double)c.P * c.B);
     return check_launch("lin32t");
   }
   GemmArgs a = base_args();
@@ -865,10 +865,10 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
     }
     // split inference modes: the role-split form (dppm_w4.hip; 0.54 ms per pair at N = 200, B = 32) unless DPPM_W3MLP=1 asks for the
     // two-group form of dppm_wsplit.h (0.57 ms), which cannot take the in_lin source and needs per-graph norm tables that fit its LDS
-    if (!save_hid && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_mlp_ok(wa)) {
+    if (!save_hid && prec != DPPM_PREC_F32 && sw(SW_DISABLE_W4) == 0 && w4_mlp_ok(wa)) {
       const int tpp = (c.P + WS_TP - 1) / WS_TP;
       const bool tables_fit = w3_contig_ok((long)c.B * tpp, tpp, (int)(8 * w3_slots(2, (long)c.B * tpp)));
-      if ((aff && !tables_fit) || inl || getenv("DPPM_W3MLP") == nullptr) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
+      if ((aff && !tables_fit) || inl || sw(SW_W3MLP) == 0) return w4_mlp_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
     }
     if (inl) return fail(DPPM_E_INVALID, "mlp_pair: the in_lin form needs the role-split kernel");
     // (Training forward: the fused exact-f32 pair below stays.  Two launches of the three-piece-split Linear would run at the HBM
@@ -879,14 +879,14 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
     if (!save_hid && prec == DPPM_PREC_BF16) return w3_mlp_forward<1>(wa, c.st);
     return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
   }
-  static const bool mlp32_off = getenv("DPPM_DISABLE_MLP32") != nullptr;   // A/B switch for measurements
+  const bool mlp32_off = sw(SW_DISABLE_MLP32) != 0;   // A/B switch for measurements
   if (H == 32 && !mlp32_off) {   // hidden-32 networks: both MLPs of the layer in one streaming launch
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
     hipLaunchKernelGGL(mlp32_fwd_kernel, dim3(cdiv((long)c.B * cdiv(c.P, 16), 4)), dim3(256), 0, c.st, x, x_bs, (const float*)q.m1_w0, (const float*)q.m2_w0,
                        (const float*)q.m1_w1, (const float*)q.m2_w1, (const float*)q.m1_b0, (const float*)q.m2_b0, (const float*)q.m1_b1, (const float*)q.m2_b1,
                        maskp, o1, o2, save_hid ? hid1 : (float*)nullptr, save_hid ? hid2 : (float*)nullptr, hs, c.P, c.B);
-    if (prof) prof_after(c.st, PROF_LINEAR, 8.0 * 32 * 32 * (double)c.P * c.B, (save_hid ? 5.0 : 3.0) * sizeof(float) * 32 * (double)c.P * c.B);
+    if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 8.0 * 32 * 32 * (double)c.P * c.B, (save_hid ? 5.0 : 3.0) * sizeof(float) * 32 * (double)c.P * c.B);
     return check_launch("mlp32_fwd");
   }
   DPPM_TRY(linear(c, H, LinArgs{q.m1_w0, H, false, x, x_bs, H}, nullptr, q.m1_b0, 1, nullptr, nullptr, 0, hid1, hs, false));
@@ -901,20 +901,14 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
   const int nsplit = wgrad_nsplit(c.B, c.P), kchunk = wgrad_kchunk(c.B, c.P);
   const int nz = c.B * nsplit;
   if ((size_t)nz * M * Nw > slab_floats) return fail(DPPM_E_INVALID, "wgrad: slab buffer too small");
-  static const bool w32_off = getenv("DPPM_DISABLE_WGRAD32") != nullptr;   // A/B switch for measurements
+  const bool w32_off = sw(SW_DISABLE_WGRAD32) != 0;   // A/B switch for measurements
   if (M == 32 && Nw == 32 && kchunk <= W32_MAXK && !w32_off && aligned16(dY) && aligned16(X) && dy_bs % 4 == 0 && x_bs % 4 == 0 && c.P % 4 == 0) {
     const size_t lds = 2 * 32 * (size_t)(kchunk + 4) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * 32 * (W32_MAXK + 4) * sizeof(float))) != hipSuccess)
-        return fail(DPPM_E_LAUNCH, "wgrad32: cannot reserve LDS");
-      attr_done = true;
-    }
+    DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&wgrad32_kernel), (size_t)((2 * 32 * (W32_MAXK + 4) * sizeof(float))), "wgrad32"));
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
     hipLaunchKernelGGL(wgrad32_kernel, dim3(nz), dim3(256), lds, c.st, dY, dy_bs, X, x_bs, c.P, nsplit, kchunk, slabs, db ? rsum : (float*)nullptr);
-    if (prof) prof_after(c.st, PROF_WGRAD, 2.0 * 32 * 32 * (double)c.P * c.B);
+    if (prof) prof_after(c.st, PROF_WGRAD, AR_F32, 2.0 * 32 * 32 * (double)c.P * c.B);
     DPPM_TRY(check_launch("wgrad32"));
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)M * Nw, RS_E) + (db ? cdiv(M, RS_E) : 0)), dim3(RS_E * RS_G), 0, c.st,
                        (const float*)slabs, nz, M, Nw, dW, ldo, (const float*)rsum, db);
@@ -940,7 +934,7 @@ int wgrad_raw(const Geo& c, int M, const float* dY, long dy_bs, int Nw, const fl
 int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float* X, long x_bs, float* dW, int ldo, float* db) {
   if (use_wstat(M) && Nw == WS_H && c.w.slab_floats >= ws_wgrad_scratch_floats()) {   // register-resident split-K form (dppm_wgrad.h)
     // three-piece split products on the bf16 pipe (float32-grade, dppm_wgrad.h); DPPM_WGRAD_F32=1 = exact-f32 MFMAs (A/B switch)
-    static const bool split = getenv("DPPM_WGRAD_F32") == nullptr;
+    const bool split = sw(SW_WGRAD_F32) == 0;
     return ws_wgrad(dY, dy_bs, X, x_bs, c.w.B, c.w.P, dW, ldo, db, c.at(c.w.slabs), c.st, split);
   }
   return wgrad_raw(Geo{c.w.B, c.w.P, c.st}, M, dY, dy_bs, Nw, X, x_bs, dW, ldo, db, c.at(c.w.slabs), c.w.slab_floats, c.at(c.w.rsum));
@@ -948,7 +942,7 @@ int wgrad(const Ctx& c, int M, const float* dY, long dy_bs, int Nw, const float*
 
 // several 32 x 32 weight gradients of the small networks in two launches (wgrad32m_kernel + reduce32m_kernel)
 bool wgrad32_multi_ok(const Ctx& c) {
-  static const bool off = getenv("DPPM_DISABLE_WGRAD32") != nullptr;
+  const bool off = sw(SW_DISABLE_WGRAD32) != 0;
   return !off && c.w.H == 32 && c.w.training && c.w.P % 4 == 0 && wgrad_kchunk(c.w.B, c.w.P) <= W32_MAXK;
 }
 int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
@@ -960,17 +954,11 @@ int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
     DPPM_REQUIRE(aligned16(jobs[j].dY) && aligned16(jobs[j].X) && jobs[j].dy_bs % 4 == 0 && jobs[j].x_bs % 4 == 0, "wgrad32_multi: unaligned operand");
   }
   const size_t lds = 2 * 32 * (size_t)(a.kchunk + 4) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad32m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(2 * 32 * (W32_MAXK + 4) * sizeof(float))) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "wgrad32_multi: cannot reserve LDS");
-    attr_done = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&wgrad32m_kernel), (size_t)((2 * 32 * (W32_MAXK + 4) * sizeof(float))), "wgrad32_multi"));
   const bool prof = prof_enabled();
   if (prof) prof_before(c.st);
   hipLaunchKernelGGL(wgrad32m_kernel, dim3(njobs * a.nz), dim3(256), lds, c.st, a);
-  if (prof) prof_after(c.st, PROF_WGRAD, 2.0 * 32 * 32 * (double)c.w.P * c.w.B * njobs);
+  if (prof) prof_after(c.st, PROF_WGRAD, AR_F32, 2.0 * 32 * 32 * (double)c.w.P * c.w.B * njobs);
   DPPM_TRY(check_launch("wgrad32m"));
   hipLaunchKernelGGL(reduce32m_kernel, dim3(njobs * 33), dim3(RS_E * RS_G), 0, c.st, a);
   return check_launch("reduce32m");
@@ -979,14 +967,14 @@ int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
 // per-plane products for all (b,c): C = op(A) * op(B) * inv_norm[b] (* mask[b])
 int plane_mm(hipStream_t st, const float* A, const float* Bm, float* C, int batch, int n, int ld, bool ta, bool tb,
              const float* scale, const float* mask, int div, int prec = DPPM_PREC_F32) {
-  static const bool strip_off = getenv("DPPM_DISABLE_STRIPMM") != nullptr;   // A/B switch for measurements
+  const bool strip_off = sw(SW_DISABLE_STRIPMM) != 0;   // A/B switch for measurements
   if ((prec == DPPM_PREC_BF16X3 || prec == DPPM_PREC_BF16) && !ta && !tb && plane3_supported(n) && aligned16(A) && aligned16(Bm) && aligned16(C)) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // forward form on the bf16 pipe (dppm_plane4.hip, dppm_planesplit.h)
     const int ns = prec == DPPM_PREC_BF16X3 ? 3 : 1;
-    if (getenv("DPPM_DISABLE_PLANE4") == nullptr && plane4_ok(pa, batch, ns, false, false)) return plane4_run(pa, batch, ns, false, false, st);
+    if (sw(SW_DISABLE_PLANE4) == 0 && plane4_ok(pa, batch, ns, false, false)) return plane4_run(pa, batch, ns, false, false, st);
     return prec == DPPM_PREC_BF16X3 ? plane3_launch<3>(pa, batch, st) : plane3_launch<1>(pa, batch, st);
   }
-  if (prec == DPPM_PREC_F32X6 && aligned16(A) && aligned16(Bm) && aligned16(C) && getenv("DPPM_DISABLE_PLANE6") == nullptr) {
+  if (prec == DPPM_PREC_F32X6 && aligned16(A) && aligned16(Bm) && aligned16(C) && sw(SW_DISABLE_PLANE6) == 0) {
     PlaneArgs pa{A, Bm, C, n, ld, scale, mask, div};   // float32-equivalent three-piece split on the bf16 pipe, all three forms (dppm_plane4.hip)
     if (plane4_ok(pa, batch, 6, ta, tb)) return plane4_run(pa, batch, 6, ta, tb, st);
   }
@@ -1128,13 +1116,13 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   // with per-tile statistics, norm_finalize_kernel turns them into a (scale, shift) table per graph and channel, and the three
   // consumers of the layer output (next layer's MLP pair and skip input, read-out head) apply it while staging.
   const int tpp = (P + WS_TP - 1) / WS_TP;
-  const bool fuse_norm = use_wstat(H) && !training && prec != DPPM_PREC_F32 && !pr->layer_cond && getenv("DPPM_DISABLE_NORMFUSE") == nullptr &&
-                         getenv("DPPM_DISABLE_HEAD3") == nullptr &&
-                         (getenv("DPPM_DISABLE_W4") == nullptr ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
+  const bool fuse_norm = use_wstat(H) && !training && prec != DPPM_PREC_F32 && !pr->layer_cond && sw(SW_DISABLE_NORMFUSE) == 0 &&
+                         sw(SW_DISABLE_HEAD3) == 0 &&
+                         (sw(SW_DISABLE_W4) == 0 ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
                           (w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
                            w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)))));
   // in_lin (K = 2) folded into layer 0's consumers: u0 is never written (one plane-set less to write, two less to read per level)
-  const bool fuse_inlin = fuse_norm && getenv("DPPM_DISABLE_W4") == nullptr && getenv("DPPM_DISABLE_INLINFUSE") == nullptr;
+  const bool fuse_inlin = fuse_norm && sw(SW_DISABLE_W4) == 0 && sw(SW_DISABLE_INLINFUSE) == 0;
   const InlSrc inl{pr->in_w, pr->in_b, cat, cat_bs};
   if (!fuse_inlin) {
     // in_lin: u0 = W_in (H x 2) * [A ; sigma I] + b     (model/ppgn.py:301)
@@ -1177,14 +1165,14 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         j.Y = cat + (size_t)(2 + l * H) * P; j.y_bs = cat_bs;
         wa.aff = naff + (size_t)(l > 0 ? l - 1 : L) * aff_sz;
         wa.stat = c.at(w.nstat); wa.cnt = c.at(w.ncnt); wa.maskstat = maskp;
-        { const char* e = getenv("DPPM_DBG"); wa.dbg = e ? atoi(e) : 0; }
+        wa.dbg = sw(SW_DBG);
         if (fuse_inlin && l == 0) {   // the skip input u0 is formed while staging
           wa.inl_w = inl.w; wa.inl_b = inl.b; wa.inl_in = inl.in; wa.inl_bs = inl.bs;
           if (!w4_lin2_ok(wa)) return fail(DPPM_E_INVALID, "dppm_ppgn_forward: the in_lin form of m4 does not apply");
         }
       }
       // split inference modes: staging waves / multiplying waves (dppm_w4.hip); DPPM_DISABLE_W4=1 keeps the two-role form of dppm_wsplit.h
-      if (!training && prec != DPPM_PREC_F32 && getenv("DPPM_DISABLE_W4") == nullptr && w4_lin2_ok(wa))
+      if (!training && prec != DPPM_PREC_F32 && sw(SW_DISABLE_W4) == 0 && w4_lin2_ok(wa))
         DPPM_TRY(w4_lin2_run(wa, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st));
       else
       DPPM_TRY(ws_lin_p(wa, 2, false, prec, c.st));
@@ -1207,11 +1195,11 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     if (prof_enabled()) prof_before(c.st);
     launch_inorm_fwd(P, B * H, c.st, (const float*)y, hs, (const float*)maskp, cat + (size_t)(2 + l * H) * P, cat_bs, H, P, (float*)nullptr,
                      c.at(w.rstd) + (size_t)l * B * H);
-    if (prof_enabled()) prof_after(c.st, PROF_NORM, 2.0 * sizeof(float) * (double)w.S, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
+    if (prof_enabled()) prof_after(c.st, PROF_NORM, AR_NONE, 2.0 * sizeof(float) * (double)w.S, 2.0 * sizeof(float) * (double)w.S);   // read y once, write u once
     DPPM_TRY(check_launch("inorm_fwd"));
   }
   // split modes, H = 128: layer_cat_lin, after_conv and final_lin in one pass over the layer outputs (dppm_head.h)
-  const bool head_off = getenv("DPPM_DISABLE_HEAD3") != nullptr;   // A/B switch for measurements and tests (read per call)
+  const bool head_off = sw(SW_DISABLE_HEAD3) != 0;   // A/B switch for measurements and tests (read per call)
   if (use_wstat(H) && !training && prec != DPPM_PREC_F32 && !head_off) {
     HeadArgs ha{cat, cat_bs, reinterpret_cast<const uint4*>(c.at(w.himg)), pr->cat_w, w.CT, pr->cat_b, pr->after_b, pr->final_w, pr->final_b,
                 logits, B, N, w.ld, P, L, fuse_norm ? naff : nullptr, fuse_norm ? maskp : nullptr};
@@ -1338,7 +1326,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
                      (const float*)maskp, (const float*)(c.at(w.rstd) + (size_t)l * B * H), dy, H, P);
     DPPM_TRY(check_launch("inorm_bwd"));
     // m4
-    const bool multi = !ws && H == 32 && getenv("DPPM_DISABLE_LIN32") == nullptr && wgrad32_multi_ok(c);   // m4's gradients ride with the MLPs' below
+    const bool multi = !ws && H == 32 && sw(SW_DISABLE_LIN32) == 0 && wgrad32_multi_ok(c);   // m4's gradients ride with the MLPs' below
     if (!multi) {
       DPPM_TRY(wgrad(c, H, dy, hs, H, mm, hs, gq.m4_w, 2 * H, gq.m4_b));
       DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gq.m4_w + H, 2 * H, nullptr));
@@ -1351,12 +1339,12 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       WsJob& j1 = wa.job[1];
       j1.X = dy; j1.x_bs = hs; j1.W1 = q.m4_w + H; j1.ldw1 = 2 * H; j1.Y = dx; j1.y_bs = dx_bs; j1.accumulate = l != 0;
       DPPM_TRY(ws_lin_p(wa, 1, true, prec, c.st));
-    } else if (H == 32 && getenv("DPPM_DISABLE_LIN32") == nullptr) {   // small networks: both halves of m4^T from one read of dy
+    } else if (H == 32 && sw(SW_DISABLE_LIN32) == 0) {   // small networks: both halves of m4^T from one read of dy
       const bool prof = prof_enabled();
       if (prof) prof_before(c.st);
       hipLaunchKernelGGL(lin32t_kernel, dim3(cdiv((long)B * cdiv(P, 16), 4)), dim3(256), 0, c.st, (const float*)q.m4_w, 2 * H, (const float*)dy, hs,
                          (const float*)nullptr, 0L, dmm, hs, P, B, 0, (const float*)(q.m4_w + H), dx, dx_bs, l != 0 ? 1 : 0);
-      if (prof) prof_after(c.st, PROF_LINEAR, 4.0 * 32 * 32 * (double)P * B);
+      if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 4.0 * 32 * 32 * (double)P * B);
       DPPM_TRY(check_launch("lin32t(m4^T)"));
     } else {
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dmm, hs, false));
@@ -1371,7 +1359,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     const float* wl0[2] = {q.m1_w0, q.m2_w0}; const float* wl1[2] = {q.m1_w1, q.m2_w1};
     float* gw0[2] = {gq.m1_w0, gq.m2_w0}; float* gb0[2] = {gq.m1_b0, gq.m2_b0};
     float* gw1[2] = {gq.m1_w1, gq.m2_w1}; float* gb1[2] = {gq.m1_b1, gq.m2_b1};
-    static const bool m32_off = getenv("DPPM_DISABLE_LIN32") != nullptr;
+    const bool m32_off = sw(SW_DISABLE_LIN32) != 0;
     if (!ws && H == 32 && !m32_off) {   // small networks: both MLP backward chains in one launch (dpre_1 -> dy, dpre_2 -> dmm, both free here)
       if (multi) {   // dy is still m4's output gradient here: four weight gradients in one launch, before dy is reused for dpre_1
         const W32Job jobs[4] = {{dy, hs, mm, hs, gq.m4_w, 2 * H, gq.m4_b}, {dy, hs, x, x_bs, gq.m4_w + H, 2 * H, nullptr},
@@ -1385,7 +1373,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       if (prof) prof_before(c.st);
       hipLaunchKernelGGL(mlp32_bwd_kernel, dim3(cdiv((long)B * cdiv(P, 16), 4)), dim3(256), 0, c.st, do1, do2, hid1, hid2, hs, wl1[0], wl1[1], wl0[0],
                          wl0[1], dy, dmm, dx, dx_bs, P, B);
-      if (prof) prof_after(c.st, PROF_LINEAR, 8.0 * 32 * 32 * (double)P * B);
+      if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 8.0 * 32 * 32 * (double)P * B);
       DPPM_TRY(check_launch("mlp32_bwd"));
       if (multi) {
         const W32Job jobs[2] = {{dy, hs, x, x_bs, gw0[0], H, gb0[0]}, {dmm, hs, x, x_bs, gw0[1], H, gb0[1]}};
@@ -1409,7 +1397,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
         WsJob& a1 = l1.job[0]; WsJob& a2 = l2.job[0];
         a1.X = dout[k]; a1.x_bs = hs; a1.W1 = wl1[k]; a1.ldw1 = H; a1.Hsaved = hid[k]; a1.hs_bs = hs; a1.Y = dpre; a1.y_bs = hs;
         a2.X = dpre; a2.x_bs = hs; a2.W1 = wl0[k]; a2.ldw1 = H; a2.Y = dx; a2.y_bs = dx_bs; a2.accumulate = 1;
-        if (getenv("DPPM_DISABLE_W6") == nullptr && getenv("DPPM_DISABLE_W6MLP") == nullptr && w6_lin_ok(l1, 1) && w6_lin_ok(l2, 1)) {
+        if (sw(SW_DISABLE_W6) == 0 && sw(SW_DISABLE_W6MLP) == 0 && w6_lin_ok(l1, 1) && w6_lin_ok(l2, 1)) {
           DPPM_TRY(w6_lin_run(l1, 1, true, c.st, PROF_WS_MLP2));
           DPPM_TRY(w6_lin_run(l2, 1, true, c.st, PROF_WS_MLP2));
         } else

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, 
 }  // namespace
 
 bool sg_supported(const dppm_ppgn_params* pr, int N) {
-  const bool off = getenv("DPPM_DISABLE_SMALLGRAPH") != nullptr;   // A/B switch for measurements and tests (read per call)
+  const bool off = sw(SW_DISABLE_SMALLGRAPH) != 0;   // A/B switch for measurements and tests (read per call)
   return !off && pr->hidden == 32 && N >= 1 && N <= SG_MAX_NODES && pr->num_layers <= SG_MAX_LAYERS && !pr->layer_cond;
 }
 
@@ -515,13 +515,8 @@ int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, co
   a.L = pr->num_layers; a.N = N; a.ld = round_up(N, 4); a.P = N * a.ld; a.CT = 2 + 32 * pr->num_layers;
   const SgSave sv = save ? *save : SgSave{};
   const size_t lds = SG_LDS_FLOATS * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "sg_forward: cannot reserve %zu bytes of LDS", lds);
-    attr_done = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&sg_forward_kernel<false>), lds, "sg_forward"));
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&sg_forward_kernel<true>), lds, "sg_forward(save)"));
   if (save) hipLaunchKernelGGL(sg_forward_kernel<true>, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
   else hipLaunchKernelGGL(sg_forward_kernel<false>, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
   return check_launch("sg_forward");
@@ -541,12 +536,7 @@ __global__ __launch_bounds__(256) void lds_fill_kernel(unsigned pattern, unsigne
 extern "C" int dppm_test_fill_lds(uint32_t pattern, void* stream) {
   using namespace dppm;
   const size_t bytes = 160 * 1024;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "dppm_test_fill_lds: cannot reserve %zu bytes of LDS", bytes);
-    attr_done = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&lds_fill_kernel), (size_t)(bytes), "dppm_test_fill_lds"));
   hipLaunchKernelGGL(lds_fill_kernel, dim3(2048), dim3(256), bytes, as_stream(stream), pattern, (unsigned)(bytes / 4), (unsigned*)nullptr);
   return check_launch("dppm_test_fill_lds");
 }

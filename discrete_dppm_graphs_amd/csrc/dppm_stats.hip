@@ -137,12 +137,7 @@ extern "C" int dppm_graph_stats(const float* adj, int B, int N, int bins, const 
   DPPM_REQUIRE(adj && edges && deg_hist && clus_hist, "dppm_graph_stats: null pointer");
   DPPM_REQUIRE(B > 0 && N > 0 && N <= 1024 && bins > 0 && bins <= 4096, "dppm_graph_stats: B=%d N=%d (<= 1024) bins=%d (<= 4096)", B, N, bins);
   const size_t lds = ((size_t)N * ((N + 31) / 32) + N + bins + 1) * 4;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(graph_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "dppm_graph_stats: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    lds_set = lds;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(graph_stats_kernel), (size_t)(lds), "dppm_graph_stats"));
   hipLaunchKernelGGL(graph_stats_kernel, dim3(B), dim3(ST_THREADS), lds, as_stream(stream), adj, N, bins, edges, deg_hist, clus_hist);
   return check_launch("dppm_graph_stats");
 }

@@ -477,22 +477,16 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
 
 template <int NS, int STG>
 static int w4_mlp_launch(const WsArgs& a, hipStream_t st) {
-  static bool set[3] = {false, false, false};
   const size_t lds = (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + (4 * 64 + 2 * 256 + 4 * 16 * WS_WIDE_PITCH) * sizeof(float);
   const bool nrm = a.aff != nullptr, inl = a.inl_w != nullptr;   // in_lin's output is not normalised: never both
-  const int which = inl ? 2 : (nrm ? 1 : 0);
   auto kern = inl ? w4_mlp_kernel<NS, false, true, STG> : (nrm ? w4_mlp_kernel<NS, true, false, STG> : w4_mlp_kernel<NS, false, false, STG>);
-  if (!set[which]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "w4_mlp: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set[which] = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds), "w4_mlp"));
   const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
   const long slots = w3_slots(a.njobs, ntiles);              // one workgroup per CU: 32 per XCD, jobs that share X on one XCD
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(64 * (STG + 8)), lds, st, a);
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
+  if (prof) prof_after(st, PROF_WS_MLP2, prof_arith_of_pieces(NS), 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
 #if W4_TRACE_ON
   if (a.dbg & 2048) {
     static int dumps = 0;
@@ -521,7 +515,7 @@ bool w4_mlp_ok(const WsArgs& a) {
 int w4_mlp_run(const WsArgs& a0, int ns, hipStream_t st) {
   WsArgs a = a0;
 #if W4_TRACE_ON
-  { const char* e = getenv("DPPM_DBG_W4"); if (e) a.dbg |= atoi(e); }
+  a.dbg |= sw(SW_DBG_W4);
 #endif
   if (!w4_mlp_ok(a)) return fail(DPPM_E_INVALID, "w4_mlp: unsupported arguments");
   // STG = 4 only: at 16 waves (STG = 8, 128 registers) the second fragment set of w4_mma8 spills inside the multiply loop
@@ -531,22 +525,16 @@ int w4_mlp_run(const WsArgs& a0, int ns, hipStream_t st) {
 
 template <int NS>
 static int w4_lin2_launch(const WsArgs& a, hipStream_t st) {
-  static bool set[3] = {false, false, false};
   const size_t lds = (size_t)2 * (NS > 1 ? 2 : 1) * W3_IMG + 2 * 64 * sizeof(float);
   const bool nrm = a.stat != nullptr, inl = a.inl_w != nullptr;   // the in_lin form always comes with the statistics (layer 0 of the fused-norm forward)
-  const int which = inl ? 2 : (nrm ? 1 : 0);
   auto kern = inl ? w4_lin2_kernel<NS, true, true> : (nrm ? w4_lin2_kernel<NS, true, false> : w4_lin2_kernel<NS, false, false>);
-  if (!set[which]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "w4_lin2: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set[which] = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds), "w4_lin2"));
   const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);       // one workgroup per CU
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), lds, st, a);
-  if (prof) prof_after(st, PROF_WS_SUM2, 4.0 * WS_H * WS_H * (double)a.P * a.B, ws_alg_bytes(a, 2, false, false));
+  if (prof) prof_after(st, PROF_WS_SUM2, prof_arith_of_pieces(NS), 4.0 * WS_H * WS_H * (double)a.P * a.B, ws_alg_bytes(a, 2, false, false));
   return check_launch("w4_lin2");
 }
 

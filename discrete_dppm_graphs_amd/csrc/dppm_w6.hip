@@ -200,20 +200,15 @@ __global__ __launch_bounds__(W6L_THREADS) void w6_lin_kernel(const WsArgs a) {
 
 template <int NSRC, bool TRANS>
 static int w6_lin_launch(const WsArgs& a, int prof_class, hipStream_t st) {
-  static bool set = false;
   const size_t lds = (size_t)2 * W6L_BUF;
   auto kern = w6_lin_kernel<NSRC, TRANS>;
-  if (!set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "w6_lin: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds), "w6_lin"));
   const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
   const long slots = w3_slots(a.njobs, ntiles);              // one workgroup per CU: 32 per XCD, jobs that share X on one XCD
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W6L_THREADS), lds, st, a);
-  if (prof) prof_after(st, prof_class, 2.0 * NSRC * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, NSRC, false, a.job[0].Hsaved != nullptr));
+  if (prof) prof_after(st, prof_class, AR_F32X6, 2.0 * NSRC * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, NSRC, false, a.job[0].Hsaved != nullptr));
   return check_launch("w6_lin");
 }
 

@@ -297,7 +297,7 @@ inline int ws_wgrad(const float* dY, long dy_bs, const float* X, long x_bs, int 
   else if (split) hipLaunchKernelGGL(ws6_wgrad_kernel<false>, dim3(grid), dim3(WG_THREADS), 0, st, a);
   else if (db) hipLaunchKernelGGL(ws_wgrad_kernel<true>, dim3(grid), dim3(WG_THREADS), 0, st, a);
   else hipLaunchKernelGGL(ws_wgrad_kernel<false>, dim3(grid), dim3(WG_THREADS), 0, st, a);
-  if (prof) prof_after(st, PROF_WGRAD, 2.0 * WS_H * WS_H * (double)P * B, 2.0 * sizeof(float) * WS_H * (double)P * B);
+  if (prof) prof_after(st, PROF_WGRAD, split ? AR_F32X6 : AR_F32, 2.0 * WS_H * WS_H * (double)P * B, 2.0 * sizeof(float) * WS_H * (double)P * B);
   DPPM_TRY(check_launch("ws_wgrad"));
   const int ne = db ? WG_SLAB : WS_H * WS_H;
   const int per = (grid + WG_ZC - 1) / WG_ZC, nzc = (grid + per - 1) / per;

@@ -472,15 +472,10 @@ inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
     if (!a.job[i].W2) return fail(DPPM_E_INVALID, "w3_mlp_forward: job %d lacks its second matrix", i);
     if (a.job[i].accumulate) return fail(DPPM_E_UNSUPPORTED, "w3_mlp_forward: accumulate is not provided");
   }
-  static bool set[2] = {false, false};
   const size_t lds = w3m_lds<NS>();
   const bool nrm = a.aff != nullptr;
   auto kern = nrm ? w3_mlp_kernel<NS, DEPTH, true> : w3_mlp_kernel<NS, DEPTH, false>;
-  if (!set[nrm]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "w3_mlp_forward: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set[nrm] = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds), "w3_mlp_forward"));
   const int tpp = (a.P + WS_TP - 1) / WS_TP;
   const long ntiles = (long)a.B * tpp;
   const long slots = w3_slots(a.njobs, ntiles);
@@ -489,7 +484,7 @@ inline int w3_mlp_forward(const WsArgs& a, hipStream_t st) {
   if (prof) prof_before(st);
   hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.njobs * slots)), dim3(W3M_THREADS), lds, st, a);
   const int rc = check_launch("w3_mlp_forward");
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
+  if (prof) prof_after(st, PROF_WS_MLP2, prof_arith_of_pieces(NS), 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, false, false));
   return rc;
 }
 
@@ -643,16 +638,11 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
 
 template <int NS>
 inline int w3_lin2(const WsArgs& a, hipStream_t st) {
-  static bool set[2] = {false, false};
   const size_t lds = (size_t)(NS > 1 ? 4 : 2) * W3_IMG + (size_t)WS_H * WS_TP * sizeof(float) + (2 * 64 + W3_TAB * 256) * sizeof(float);
   const bool nrm = a.stat != nullptr;
   if (nrm && (!a.cnt || !a.maskstat || !a.aff || a.njobs != 1)) return fail(DPPM_E_INVALID, "w3_lin2: statistics need aff, cnt, maskstat and a single job");
   auto kern = nrm ? w3_lin2_kernel<NS, true> : w3_lin2_kernel<NS, false>;
-  if (!set[nrm]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "w3_lin2: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    set[nrm] = true;
-  }
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), (size_t)(lds), "w3_lin2"));
   const int tpp = (a.P + WS_TP - 1) / WS_TP;
   const long ntiles = (long)a.B * tpp;
   const long slots = w3_slots(a.njobs, ntiles);
@@ -670,16 +660,15 @@ inline int w3_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   if (nsrc == 2)
     for (int i = 0; i < a.njobs; ++i)
       if (!a.job[i].X2 || !a.job[i].W2 || !ws_al16(a.job[i].X2) || a.job[i].x2_bs % 4) return fail(DPPM_E_INVALID, "w3_lin: job %d lacks its second source", i);
-  static bool set[4] = {false, false, false, false};
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   int rc;
-  if (nsrc == 1) rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 1, true>, w3_lds<NS>(), a, st, set[0], "w3_lin<1,T>")
-                            : ws_launch_kernel(w3_lin_kernel<NS, 1, false>, w3_lds<NS>(), a, st, set[1], "w3_lin<1,N>");
+  if (nsrc == 1) rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 1, true>, w3_lds<NS>(), a, st, "w3_lin<1,T>")
+                            : ws_launch_kernel(w3_lin_kernel<NS, 1, false>, w3_lds<NS>(), a, st, "w3_lin<1,N>");
   else if (!trans && (NS > 1 || a.stat)) rc = w3_lin2<NS>(a, st);   // the split form of two matrices does not fit one wave's registers; the fused-norm form lives there
-  else rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 2, true>, w3_lds<NS>(), a, st, set[2], "w3_lin<2,T>")
-                  : ws_launch_kernel(w3_lin_kernel<NS, 2, false>, w3_lds<NS>(), a, st, set[3], "w3_lin<2,N>");
-  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));
+  else rc = trans ? ws_launch_kernel(w3_lin_kernel<NS, 2, true>, w3_lds<NS>(), a, st, "w3_lin<2,T>")
+                  : ws_launch_kernel(w3_lin_kernel<NS, 2, false>, w3_lds<NS>(), a, st, "w3_lin<2,N>");
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, prof_arith_of_pieces(NS), 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));
   return rc;
 }
 

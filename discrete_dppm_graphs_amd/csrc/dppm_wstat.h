@@ -412,12 +412,8 @@ inline int ws_grid(int njobs, long ntiles) {
 }
 
 template <typename K>
-inline int ws_launch_kernel(K kernel, size_t lds, const WsArgs& a, hipStream_t st, bool& attr_set, const char* what) {
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(DPPM_E_LAUNCH, "%s: cannot raise the dynamic LDS limit to %zu bytes", what, lds);
-    attr_set = true;
-  }
+inline int ws_launch_kernel(K kernel, size_t lds, const WsArgs& a, hipStream_t st, const char* what) {
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kernel), lds, what));
   const long ntiles = (long)a.B * ((a.P + WS_TP - 1) / WS_TP);
   hipLaunchKernelGGL(kernel, dim3(ws_grid(a.njobs, ntiles)), dim3(WS_THREADS), lds, st, a);
   return check_launch(what);
@@ -464,12 +460,11 @@ inline int ws_mlp_forward(const WsArgs& a, bool save_mid, hipStream_t st) {
     if (!a.job[i].W2) return fail(DPPM_E_INVALID, "ws_mlp_forward: job %d lacks its second matrix", i);
     if (save_mid && (!a.job[i].Mid || !ws_al16(a.job[i].Mid) || a.job[i].mid_bs % 4)) return fail(DPPM_E_INVALID, "ws_mlp_forward: job %d: bad Mid", i);
   }
-  static bool set0 = false, set1 = false;
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  const int rc = save_mid ? ws_launch_kernel(ws_mlp_kernel<false, false, true>, ws_mlp_lds(), a, st, set1, "ws_mlp_forward(save)")
-                          : ws_launch_kernel(ws_mlp_kernel<false, false, false>, ws_mlp_lds(), a, st, set0, "ws_mlp_forward");
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, save_mid, false));
+  const int rc = save_mid ? ws_launch_kernel(ws_mlp_kernel<false, false, true>, ws_mlp_lds(), a, st, "ws_mlp_forward(save)")
+                          : ws_launch_kernel(ws_mlp_kernel<false, false, false>, ws_mlp_lds(), a, st, "ws_mlp_forward");
+  if (prof) prof_after(st, PROF_WS_MLP2, AR_F32, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, save_mid, false));
   return rc;
 }
 
@@ -480,11 +475,10 @@ inline int ws_mlp_backward(const WsArgs& a, hipStream_t st) {
     if (!a.job[i].W2 || !a.job[i].Hsaved || !a.job[i].Mid || !ws_al16(a.job[i].Hsaved) || !ws_al16(a.job[i].Mid) || a.job[i].hs_bs % 4 ||
         a.job[i].mid_bs % 4)
       return fail(DPPM_E_INVALID, "ws_mlp_backward: job %d needs W2 and 16-byte aligned Hsaved and Mid", i);
-  static bool set = false;
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
-  const int rc = ws_launch_kernel(ws_mlp_kernel<true, true, true>, ws_mlp_lds(), a, st, set, "ws_mlp_backward");
-  if (prof) prof_after(st, PROF_WS_MLP2, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, true, true));
+  const int rc = ws_launch_kernel(ws_mlp_kernel<true, true, true>, ws_mlp_lds(), a, st, "ws_mlp_backward");
+  if (prof) prof_after(st, PROF_WS_MLP2, AR_F32, 4.0 * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, 1, true, true));
   return rc;
 }
 
@@ -495,15 +489,14 @@ inline int ws_lin(const WsArgs& a, int nsrc, bool trans, hipStream_t st) {
   if (nsrc == 2)
     for (int i = 0; i < a.njobs; ++i)
       if (!a.job[i].X2 || !a.job[i].W2 || !ws_al16(a.job[i].X2) || a.job[i].x2_bs % 4) return fail(DPPM_E_INVALID, "ws_lin: job %d lacks its second source", i);
-  static bool set[4] = {false, false, false, false};
   const bool prof = prof_enabled();
   if (prof) prof_before(st);
   int rc;
-  if (nsrc == 1) rc = trans ? ws_launch_kernel(ws_lin_kernel<1, true>, ws_lin_lds(), a, st, set[0], "ws_lin<1,T>")
-                            : ws_launch_kernel(ws_lin_kernel<1, false>, ws_lin_lds(), a, st, set[1], "ws_lin<1,N>");
-  else rc = trans ? ws_launch_kernel(ws_lin_kernel<2, true>, ws_lin_lds(), a, st, set[2], "ws_lin<2,T>")
-                  : ws_launch_kernel(ws_lin_kernel<2, false>, ws_lin_lds(), a, st, set[3], "ws_lin<2,N>");
-  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));
+  if (nsrc == 1) rc = trans ? ws_launch_kernel(ws_lin_kernel<1, true>, ws_lin_lds(), a, st, "ws_lin<1,T>")
+                            : ws_launch_kernel(ws_lin_kernel<1, false>, ws_lin_lds(), a, st, "ws_lin<1,N>");
+  else rc = trans ? ws_launch_kernel(ws_lin_kernel<2, true>, ws_lin_lds(), a, st, "ws_lin<2,T>")
+                  : ws_launch_kernel(ws_lin_kernel<2, false>, ws_lin_lds(), a, st, "ws_lin<2,N>");
+  if (prof) prof_after(st, nsrc == 2 ? PROF_WS_SUM2 : PROF_WS_COLS, AR_F32, 2.0 * nsrc * WS_H * WS_H * (double)a.P * a.B * a.njobs, ws_alg_bytes(a, nsrc, false, false));
   return rc;
 }
 

@@ -1,6 +1,7 @@
 """Torch-tensor front end of the C-ABI (include/dppm_hip.h).  torch is used only as the owner of device memory and
 of the current HIP stream; every function validates its operands on the host (shape, dtype, device, contiguity)
 before a raw pointer reaches a kernel, and raises RuntimeError on a non-zero status.  No CPU path exists."""
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -387,12 +388,40 @@ def prof_begin(max_records=200000):
     check(lib.dppm_prof_begin(int(max_records)), "dppm_prof_begin")
 
 
+PROF_ARITH = ("f32", "bf16x3", "bf16", "f32x6", "none")   # the arithmetic a timed launch ran in (include/dppm_hip_debug.h)
+
+
 def prof_end():
-    """-> {class: {"ms": device time, "work": FLOPs (bytes for inorm), "bytes": algorithmic HBM bytes, "launches": n}},
-    truncated flag."""
-    n = len(PROF_CLASSES)
+    """-> {(class, arith): {"ms": device time, "work": FLOPs (bytes for inorm), "bytes": algorithmic HBM bytes, "launches": n}} for
+    every (kernel class, arithmetic) pair that saw a launch, and the truncated flag."""
+    nc, na = len(PROF_CLASSES), len(PROF_ARITH)
+    n = nc * na
     ms, work, nbytes, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_long * n)()
-    rc = lib.dppm_prof_end(ms, work, nbytes, cnt, n)
+    rc = lib.dppm_prof_end(ms, work, nbytes, cnt, nc, na)
     if rc < 0:
         check(rc, "dppm_prof_end")
-    return {k: {"ms": ms[i], "work": work[i], "bytes": nbytes[i], "launches": cnt[i]} for i, k in enumerate(PROF_CLASSES)}, rc == 1
+    out = {}
+    for i, k in enumerate(PROF_CLASSES):
+        for j, a in enumerate(PROF_ARITH):
+            if cnt[i * na + j]:
+                out[(k, a)] = {"ms": ms[i * na + j], "work": work[i * na + j], "bytes": nbytes[i * na + j], "launches": cnt[i * na + j]}
+    return out, rc == 1
+
+
+def debug_set(name, value):
+    """Experiment switch of the library (include/dppm_hip_debug.h); returns the previous value."""
+    old = C.c_int(0)
+    check(lib.dppm_debug_get(name.encode(), C.byref(old)), "dppm_debug_get")
+    check(lib.dppm_debug_set(name.encode(), int(value)), "dppm_debug_set")
+    return old.value
+
+
+@contextlib.contextmanager
+def debug_switch(**switches):
+    """with ops.debug_switch(DISABLE_HEAD3=1): ...   -- tests and A/B measurements only."""
+    old = {k: debug_set(k, v) for k, v in switches.items()}
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            debug_set(k, v)

@@ -260,25 +260,7 @@ size_t dppm_mmd_workspace_bytes(int n1, int n2);
 int dppm_mmd_gaussian_emd(const float* h1, int n1, const float* h2, int n2, int bins, double sigma, double distance_scaling,
                           double* out4, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ------------------------------------------------------------------------------------------------
- * Measurement hooks (no counterpart in the reference; used by bench.py only).
- * dppm_prof_begin arms per-launch HIP-event timing of the GEMM-family and norm kernels (events are recorded on the
- * stream each kernel is launched on); dppm_prof_end waits for them and returns, per kernel class
- * (0 = per-position linear layers on the generic GEMM, 1 = per-channel N x N contraction, 2 = weight-gradient GEMMs,
- * 3 = instance norm, 4 / 5 / 6 = weight-stationary kernels: fused MLP pair / skip-concat Linear / single Linear,
- * 7 = fused read-out head),
- * the summed device time [ms], the summed algorithmic work (FLOPs; bytes for 3), the summed algorithmic HBM bytes (every distinct
- * operand read once, every result written once; 0 for the generic GEMM class) and the launch count (nclass >= 8).
- * Returns 1 if more than max_records launches happened (totals then cover the first max_records only).
- * Process-global, not thread-safe; arm it from one thread with no other caller active.
- * ---------------------------------------------------------------------------------------------- */
-int dppm_prof_begin(int max_records);
-int dppm_prof_end(double* ms_per_class_host, double* work_per_class_host, double* bytes_per_class_host,
-                  long* launches_per_class_host, int nclass);
-
-/* Test hook (no counterpart in the reference): 2048 workgroups each overwrite 160 KiB of LDS with `pattern`, so that a
- * following kernel that reads LDS it never wrote sees that pattern (tests poison the LDS with NaN bits). */
-int dppm_test_fill_lds(uint32_t pattern, void* stream);
+/* Measurement and test hooks (per-launch timing, LDS poison, experiment switches) are NOT part of this interface: include/dppm_hip_debug.h. */
 
 #ifdef __cplusplus
 }

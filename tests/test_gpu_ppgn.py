@@ -334,7 +334,7 @@ def test_plane_matmul_reduced_precision(ops, n, precision, tol):
 
 
 @pytest.mark.parametrize("n,batch", [(200, 600), (203, 300), (150, 257), (224, 70), (225, 64), (256, 100), (300, 129), (450, 65), (512, 70)])
-def test_plane_matmul_persistent_stream(ops, n, batch, monkeypatch):
+def test_plane_matmul_persistent_stream(ops, n, batch):
     """The role-split contraction (dppm_plane4.hip) walks several planes per workgroup as one stream of K panels (batch > 256
     workgroups, uneven shares; N > 224: 2 x 2 output blocks per plane, four workgroups in step): bit-identical to the
     one-block-per-workgroup kernel of dppm_planesplit.h, and right in float64."""
@@ -346,10 +346,9 @@ def test_plane_matmul_persistent_stream(ops, n, batch, monkeypatch):
     Bm[:, :, :n] = rng.normal(size=(batch, n, n))
     scale = rng.uniform(0.5, 2, size=batch).astype(np.float32)
     for precision, tol in (("bf16x3", 3e-5), ("bf16", 2e-2)):
-        monkeypatch.delenv("DPPM_DISABLE_PLANE4", raising=False)
         out = ops.plane_matmul(dev(A), dev(Bm), n, scale=dev(scale), scale_div=1, precision=precision).cpu().numpy()
-        monkeypatch.setenv("DPPM_DISABLE_PLANE4", "1")
-        old = ops.plane_matmul(dev(A), dev(Bm), n, scale=dev(scale), scale_div=1, precision=precision).cpu().numpy()
+        with ops.debug_switch(DISABLE_PLANE4=1):
+            old = ops.plane_matmul(dev(A), dev(Bm), n, scale=dev(scale), scale_div=1, precision=precision).cpu().numpy()
         assert np.array_equal(out, old)
         sel = rng.choice(batch, size=8, replace=False)
         ref = (A[sel, :, :n].astype(np.float64) @ Bm[sel, :, :n].astype(np.float64)) * scale[sel, None, None]
@@ -414,12 +413,8 @@ def test_mlp_pair_block(ops, H, P, B, save):
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 5e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("P,B", [(64, 1), (1188, 3), (40000, 1)])
 @pytest.mark.parametrize("form", ["role_split", "two_group"])   # dppm_w4.hip (default) / dppm_wsplit.h (DPPM_W3MLP=1)
-def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B, form, monkeypatch):
+def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B, form):
     H = 128
-    if form == "two_group":
-        monkeypatch.setenv("DPPM_W3MLP", "1")
-    else:
-        monkeypatch.delenv("DPPM_W3MLP", raising=False)
     rng = np.random.default_rng(P)
     X = rng.normal(size=(B, H, P)).astype(np.float32)
     maskp = (rng.random((B, P)) < 0.8).astype(np.float32)
@@ -428,7 +423,8 @@ def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B, form, monke
         for k in ("0", "2"):
             Wt[f"{m}.{k}.weight"] = (rng.normal(size=(H, H)) / np.sqrt(H)).astype(np.float32)
             Wt[f"{m}.{k}.bias"] = rng.normal(size=H).astype(np.float32)
-    o1, o2, _, _ = ops.mlp_pair_fwd(dev(X), {k: dev(v) for k, v in Wt.items()}, maskp=dev(maskp), precision=precision)
+    with ops.debug_switch(W3MLP=int(form == "two_group")):
+        o1, o2, _, _ = ops.mlp_pair_fwd(dev(X), {k: dev(v) for k, v in Wt.items()}, maskp=dev(maskp), precision=precision)
     X64 = X.astype(np.float64)
     for m, o in (("m1", o1), ("m2", o2)):
         pre = np.einsum("ok,bkp->bop", Wt[f"{m}.0.weight"].astype(np.float64), X64) + Wt[f"{m}.0.bias"][None, :, None]
@@ -490,31 +486,19 @@ def test_adam_matches_torch(ops):
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-7)
 
 
-def test_split_wgrad_vs_exact():
+def test_split_wgrad_vs_exact(ops):
     """The default weight-gradient kernel (three-piece bf16 split, six MFMAs per product) against the exact-float32 MFMA kernel
-    (DPPM_WGRAD_F32=1, read once per process, hence the child processes): float32-grade agreement, 2e-5 of each weight tensor's
+    (switch WGRAD_F32 of include/dppm_hip_debug.h): float32-grade agreement, 2e-5 of each weight tensor's
     scale; the bias gradients are plain float32 row sums in both kernels and differ by summation order only (2e-4)."""
-    import subprocess
-    import sys
-    code = r'''
-import numpy as np, torch, sys
-sys.path.insert(0, %r)
-from tests.test_gpu_ppgn import rand_case, run_gpu
-from discrete_dppm_graphs_amd import ops
-from oracle import ppgn as op
-rng = np.random.default_rng(1)
-A, mask = rand_case(rng, 2, 72)
-W = op.init_weights(2, 128, seed=4)
-R = rng.normal(size=A.shape).astype(np.float32) * mask
-_, g = run_gpu(ops, W, A, mask, [0.1, 0.3], 2, 128, dlogits=R)
-np.savez(sys.argv[1], **g)
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import tempfile
+    from oracle import ppgn as op
+    rng = np.random.default_rng(1)
+    A, mask = rand_case(rng, 2, 72)
+    W = op.init_weights(2, 128, seed=4)
+    R = rng.normal(size=A.shape).astype(np.float32) * mask
     outs = []
-    for env in ({"DPPM_WGRAD_F32": "1"}, {}):
-        with tempfile.NamedTemporaryFile(suffix=".npz") as f:
-            subprocess.check_call([sys.executable, "-c", code, f.name], env={**os.environ, **env})
-            outs.append(dict(np.load(f.name)))
+    for exact in (1, 0):
+        with ops.debug_switch(WGRAD_F32=exact):
+            outs.append(run_gpu(ops, W, A, mask, [0.1, 0.3], 2, 128, dlogits=R)[1])
     gmax = max(np.abs(v).max() for v in outs[0].values())
     differs = False
     for k in outs[0]:
@@ -565,11 +549,8 @@ def test_fused_head_vs_layered_readout(ops, precision, tol, B, N, L):
     sigma = rng.uniform(0, 0.5, size=B)
     W = op.init_weights(L, H, seed=N + L)
     got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    os.environ["DPPM_DISABLE_HEAD3"] = "1"
-    try:
+    with ops.debug_switch(DISABLE_HEAD3=1):
         layered, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    finally:
-        del os.environ["DPPM_DISABLE_HEAD3"]
     close(got, layered, tol=tol)
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
@@ -589,11 +570,8 @@ def test_inlin_formed_while_staging(ops, precision, tol, B, N, L):
     sigma = rng.uniform(0, 0.5, size=B)
     W = op.init_weights(L, H, seed=N + 5 * L)
     got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    os.environ["DPPM_DISABLE_INLINFUSE"] = "1"
-    try:
+    with ops.debug_switch(DISABLE_INLINFUSE=1):
         plain, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    finally:
-        del os.environ["DPPM_DISABLE_INLINFUSE"]
     assert np.isfinite(got).all()
     close(got, plain, tol=tol)
     # the effect this form once had (packed in_lin rows, DESIGN.md section 4 "The in_lin stagers") came and went from run to run
@@ -620,22 +598,43 @@ def test_fused_instance_norm_vs_standalone_pass(ops, precision, tol, B, N, L):
     sigma = rng.uniform(0, 0.5, size=B)
     W = op.init_weights(L, H, seed=N + 3 * L)
     got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    os.environ["DPPM_W3MLP"] = "1"                           # the two-group MLP where its tables fit (the role-split one elsewhere)
-    try:
+    with ops.debug_switch(W3MLP=1):
         got3, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    finally:
-        del os.environ["DPPM_W3MLP"]
-    os.environ["DPPM_DISABLE_NORMFUSE"] = "1"
-    try:
+    with ops.debug_switch(DISABLE_NORMFUSE=1):
         plain, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision=precision)
-    finally:
-        del os.environ["DPPM_DISABLE_NORMFUSE"]
     assert np.isfinite(got).all() and np.isfinite(got3).all()
     close(got, plain, tol=tol)
     close(got3, plain, tol=tol)
     with torch.no_grad():
         ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
     close(got, ref, tol=1e-3 if precision == "bf16x3" else 1.5e-1)
+
+
+@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (2, 130, 2)])
+def test_fallback_forms_behind_switches(ops, B, N, L):
+    """The older kernels that the experiment switches of include/dppm_hip_debug.h select stay correct: inference with DISABLE_W4 (the
+    two-group forms of dppm_wsplit.h incl. the fused-norm m4, w3_lin2_kernel<., true>) against the default forward, and training
+    gradients with DISABLE_W6 + DISABLE_W6MLP + DISABLE_PLANE6 (exact-f32 linears and contraction) against the default
+    (f32x6 on the bf16 pipe): float32-grade agreement."""
+    from oracle import ppgn as op
+    H = 128
+    rng = np.random.default_rng(5100 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 11 * L)
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    with ops.debug_switch(DISABLE_W4=1):
+        old, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    close(got, old, tol=5e-5)
+    R = rng.normal(size=A.shape).astype(np.float32) * mask
+    lg, g = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
+    with ops.debug_switch(DISABLE_W6=1, DISABLE_W6MLP=1, DISABLE_PLANE6=1):
+        lg0, g0 = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
+    close(lg, lg0, tol=2e-5)
+    gmax = max(np.abs(v).max() for v in g0.values())
+    for k in g0:
+        scale = max(np.abs(g0[k]).max(), 2e-2 * gmax)
+        assert np.abs(g[k] - g0[k]).max() <= 2e-4 * scale, k
 
 
 @pytest.mark.parametrize("B,N,L", [(5, 64, 3), (3, 50, 2), (2, 200, 2), (1, 300, 2), (40, 24, 2)])

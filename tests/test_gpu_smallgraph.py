@@ -19,11 +19,8 @@ def ops():
 
 
 def _general(ops, *args):
-    os.environ["DPPM_DISABLE_SMALLGRAPH"] = "1"
-    try:
+    with ops.debug_switch(DISABLE_SMALLGRAPH=1):
         return run_gpu(ops, *args)[0]
-    finally:
-        del os.environ["DPPM_DISABLE_SMALLGRAPH"]
 
 
 @pytest.mark.parametrize("B,N,L", [(1, 1, 1), (2, 2, 2), (3, 4, 1), (2, 5, 3), (4, 12, 2), (3, 16, 6), (5, 17, 2), (32, 18, 6), (32, 20, 6),

@@ -24,12 +24,10 @@ def oracle(dt):
 l64, g64 = oracle(torch.float64)
 l32, g32 = oracle(torch.float32)
 gmax = max(np.abs(v).max() for v in g64.values())
-SW = ("DPPM_DISABLE_W6", "DPPM_DISABLE_W6MLP", "DPPM_DISABLE_W6MLP_FWD", "DPPM_DISABLE_W6MLP_BWD", "DPPM_DISABLE_PLANE6", "DPPM_WGRAD_F32")
 for tag, env in [("all exact f32", ("DPPM_DISABLE_W6", "DPPM_DISABLE_PLANE6", "DPPM_WGRAD_F32")), ("round-1 (wgrad split)", ("DPPM_DISABLE_W6", "DPPM_DISABLE_PLANE6")),
-                 ("+plane6", ("DPPM_DISABLE_W6",)), ("+w6 cols", ("DPPM_DISABLE_W6MLP",)), ("+mlp bwd", ("DPPM_DISABLE_W6MLP_FWD",)), ("+mlp fwd (all)", ())]:
-    for k in SW: os.environ.pop(k, None)
-    for k in env: os.environ[k] = "1"
-    logits, grads = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=Rr)
+                 ("+plane6", ("DPPM_DISABLE_W6",)), ("+w6 cols", ("DPPM_DISABLE_W6MLP",)), ("all on the bf16 pipe", ())]:
+    with ops.debug_switch(**{k[5:]: 1 for k in env}):
+        logits, grads = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=Rr)
     worst = []
     for n in g64:
         scale = max(np.abs(g64[n]).max(), 2e-2 * gmax)

@@ -21,9 +21,8 @@ for sh in [(8.0, 8.0, 8.0), (-8.0, -8.0, -8.0), (8.0, -8.0, -8.0), (0.0, 0.0, 0.
     sc = np.abs(l64).max()
     res = {}
     for tag, env in [("fused", {}), ("standalone", {"DPPM_DISABLE_NORMFUSE": "1"}), ("w3fused", {"DPPM_DISABLE_W4": "1"}), ("fused_exactstats", {"DPPM_DBG": "4"})]:
-        for k in ("DPPM_DISABLE_NORMFUSE", "DPPM_DISABLE_W4", "DPPM_DBG"): os.environ.pop(k, None)
-        os.environ.update(env)
-        res[tag], _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+        with ops.debug_switch(**{k[5:]: int(v) for k, v in env.items()}):
+            res[tag], _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
     m = mask.astype(bool) if mask.dtype != bool else mask
     print(sh, "scale", sc, {k: float(np.abs(v - l64).max() / sc) for k, v in res.items()},
           "fused-standalone", float(np.abs(res["fused"] - res["standalone"]).max() / sc))

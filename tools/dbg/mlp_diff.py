@@ -12,9 +12,8 @@ sigma = rng.uniform(0, 0.5, size=B)
 W = op.init_weights(L, H, seed=N + 3 * L)
 outs = {}
 for form in ("w4", "w4b", "w4c", "w3", "w3b", "w3c"):
-    if form.startswith("w3"): os.environ["DPPM_W3MLP"] = "1"
-    outs[form], _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
-    os.environ.pop("DPPM_W3MLP", None)
+    with ops.debug_switch(W3MLP=int(form.startswith("w3"))):
+        outs[form], _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
 print("w4 run-to-run max diff", np.abs(outs["w4"] - outs["w4b"]).max(), np.abs(outs["w4"] - outs["w4c"]).max(), " w3 run-to-run", np.abs(outs["w3"] - outs["w3b"]).max(), np.abs(outs["w3"] - outs["w3c"]).max())
 d = np.abs(outs["w4"] - outs["w3"])
 print("w4 vs w3 max diff", d.max(), "scale", np.abs(outs["w3"]).max())

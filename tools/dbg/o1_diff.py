@@ -26,8 +26,8 @@ def run():
     torch.cuda.synchronize()
     return ws[off_tmp1:off_tmp1 + S].cpu().numpy().reshape(B, H, P)
 got = run()
-os.environ["DPPM_DISABLE_INLINFUSE"] = "1"
-ref = run()
+with ops.debug_switch(DISABLE_INLINFUSE=1):
+    ref = run()
 d = np.abs(got - ref); sc = np.abs(ref[np.isfinite(ref)]).max()
 print("o1 max diff", np.nanmax(d), "scale", sc, "nan in got", np.isnan(got).sum(), "nan in ref", np.isnan(ref).sum())
 bad = np.argwhere(d > 1e-3 * sc)

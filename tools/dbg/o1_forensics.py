@@ -29,8 +29,8 @@ def run():
     torch.cuda.synchronize()
     return ws[off_tmp1:off_tmp1 + S].cpu().numpy().reshape(B, H, P)
 got = run()
-os.environ["DPPM_DISABLE_INLINFUSE"] = "1"
-ref = run()
+with ops.debug_switch(DISABLE_INLINFUSE=1):
+    ref = run()
 print("nan in got", int(np.isnan(got).sum()), "nan in ref", int(np.isnan(ref).sum()))
 d = np.abs(got - ref); sc = np.abs(ref).max()
 badpos = np.argwhere((d > 1e-4 * sc).any(axis=1))          # (graph, position)
