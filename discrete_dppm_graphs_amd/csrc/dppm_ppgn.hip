@@ -749,6 +749,255 @@ __global__ __launch_bounds__(256) void mlp32_fwd_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Hidden-32 networks at N > 20, "wide" forms: one wave per 64 consecutive positions, 16-byte accesses.
+// v_mfma_f32_16x16x4_f32 as D = W * X: A operand lane (q, n) = W[16 co + n][k], B operand lane (q, n) = X[k][column n], k = 4 q + r
+// within a 16-channel block ci.  A column of a tile may be ANY position, so tile j takes the positions 4 n + j of the wave's 64:
+// lane (q, n) then loads, per channel 16 ci + 4 q + r, ONE float4 (positions 4 n .. 4 n + 3 = one value for each of the four tiles), a
+// row of 16 lanes reads 256 contiguous bytes, and the result lane (q, n) of tile j holds channels 4 q + r of position 4 n + j: again one
+// float4 per channel over the four tiles.  The 16-position form above (mlp32_fwd_kernel) moves 64-byte row pieces with dword accesses.
+// Results feed the next product from registers in the result layout (the chaining of mlp32_bwd_kernel).
+struct W32 { float w[2][4][2]; };                            // [ci][r][co] = W[16 co + n][16 ci + 4 q + r]
+__device__ __forceinline__ W32 w32_load(const float* __restrict__ W, int ldw, int q, int n) {
+  W32 f;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int co = 0; co < 2; ++co) f.w[ci][r][co] = W[(size_t)(16 * co + n) * ldw + 16 * ci + 4 * q + r];
+  return f;
+}
+struct X32 { float4 v[2][4]; };                              // [ci][r]: channel 16 ci + 4 q + r, positions 4 n .. 4 n + 3
+__device__ __forceinline__ X32 x32_load(const float* __restrict__ Xp, int P, int q, int n, bool ok) {   // Xp: channel 0 at the wave's first position
+  X32 x;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      x.v[ci][r] = ok ? *reinterpret_cast<const float4*>(Xp + (size_t)(16 * ci + 4 * q + r) * P + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return x;
+}
+__device__ __forceinline__ float f4_at(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+struct A32 { floatx4 a[4][2]; };                             // [tile j][co]: element r = channel 16 co + 4 q + r of position 4 n + j
+__device__ __forceinline__ void a32_zero(A32& a) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int co = 0; co < 2; ++co) a.a[j][co] = floatx4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void a32_mma(A32& a, const W32& w, const X32& x) {
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) a.a[j][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w[ci][r][co], f4_at(x.v[ci][r], j), a.a[j][co], 0, 0, 0);
+}
+// the same with the B operand taken from a result in registers (channel block ci of the source = result block co)
+__device__ __forceinline__ void a32_mma_chain(A32& a, const W32& w, const A32& t) {
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) a.a[j][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w[ci][r][co], t.a[j][ci][r], a.a[j][co], 0, 0, 0);
+}
+// channel (co, r) of the four tiles as one float4 (positions 4 n .. 4 n + 3)
+__device__ __forceinline__ float4 a32_row(const A32& a, int co, int r) { return make_float4(a.a[0][co][r], a.a[1][co][r], a.a[2][co][r], a.a[3][co][r]); }
+__device__ __forceinline__ void a32_store(const A32& a, float* __restrict__ Yp, int P, int q, int n, bool ok) {
+  if (!ok) return;
+#pragma unroll
+  for (int co = 0; co < 2; ++co)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(Yp + (size_t)(16 * co + 4 * q + r) * P + 4 * n) = a32_row(a, co, r);
+}
+__device__ __forceinline__ void a32_bias(A32& a, const float* __restrict__ b, int q) {
+  if (!b) return;
+#pragma unroll
+  for (int co = 0; co < 2; ++co)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float bv = b[16 * co + 4 * q + r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a.a[j][co][r] += bv;
+    }
+}
+__device__ __forceinline__ void a32_leaky(A32& a) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float v = a.a[j][co][r]; a.a[j][co][r] = v > 0.f ? v : kSlope * v; }
+}
+// wave -> (graph, first position) of its 64-position group g; P % 4 == 0, a group never crosses a graph
+struct G32 { int b, p0; bool ok; };
+__device__ __forceinline__ G32 g32_of(int g, int gpp, int P, int n) {
+  G32 r;
+  r.b = g / gpp; r.p0 = 64 * (g - r.b * gpp); r.ok = r.p0 + 4 * n < P;
+  return r;
+}
+
+// both per-position MLPs of a hidden-32 layer (model/ppgn.py:58-59), wide form of mlp32_fwd_kernel; persistent waves, both MLPs'
+// four matrices resident in registers (64)
+__global__ __launch_bounds__(256) void mlp32w_fwd_kernel(const float* __restrict__ X, long x_bs,
+                                                         const float* __restrict__ W0a, const float* __restrict__ W0b,
+                                                         const float* __restrict__ W1a, const float* __restrict__ W1b,
+                                                         const float* __restrict__ b0a, const float* __restrict__ b0b,
+                                                         const float* __restrict__ b1a, const float* __restrict__ b1b,
+                                                         const float* __restrict__ maskp, float* __restrict__ o1, float* __restrict__ o2,
+                                                         float* __restrict__ hid1, float* __restrict__ hid2, long hs, int P, int B) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int gpp = (P + 63) >> 6, ngroups = B * gpp;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
+  const W32 w0a = w32_load(W0a, 32, q, n), w0b = w32_load(W0b, 32, q, n), w1a = w32_load(W1a, 32, q, n), w1b = w32_load(W1b, 32, q, n);
+  if (wave0 >= ngroups) return;
+  G32 nx = g32_of(wave0, gpp, P, n);
+  X32 xn = x32_load(X + (size_t)nx.b * x_bs + nx.p0, P, q, n, nx.ok);
+  for (int g = wave0; g < ngroups; g += nwaves) {
+    const G32 at = nx;
+    const X32 x = xn;
+    if (g + nwaves < ngroups) {                              // the next group's source is in flight during this group's products
+      nx = g32_of(g + nwaves, gpp, P, n);
+      xn = x32_load(X + (size_t)nx.b * x_bs + nx.p0, P, q, n, nx.ok);
+    }
+    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (maskp && at.ok) mk = *reinterpret_cast<const float4*>(maskp + (size_t)at.b * P + at.p0 + 4 * n);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      A32 t, acc;
+      a32_zero(t);
+      a32_mma(t, k ? w0b : w0a, x);
+      a32_bias(t, k ? b0b : b0a, q);
+      a32_leaky(t);
+      float* hid = k ? hid2 : hid1;
+      if (hid) a32_store(t, hid + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
+      a32_zero(acc);
+      a32_mma_chain(acc, k ? w1b : w1a, t);
+      a32_bias(acc, k ? b1b : b1a, q);
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc.a[0][co][r] *= mk.x; acc.a[1][co][r] *= mk.y; acc.a[2][co][r] *= mk.z; acc.a[3][co][r] *= mk.w; }
+      a32_store(acc, (k ? o2 : o1) + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
+    }
+  }
+}
+
+// m4 of a hidden-32 layer on cat(mm, x) (model/ppgn.py:66-69): Y = W[:, 0:32] mm + W[:, 32:64] x + b, both halves resident (32 registers)
+__global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                       const float* __restrict__ X1, long x1_bs, const float* __restrict__ X2, long x2_bs,
+                                                       float* __restrict__ Y, long y_bs, int P, int B) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int gpp = (P + 63) >> 6, ngroups = B * gpp;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
+  const W32 wa = w32_load(W, ldw, q, n), wb = w32_load(W + 32, ldw, q, n);
+  if (wave0 >= ngroups) return;
+  G32 nx = g32_of(wave0, gpp, P, n);
+  X32 x1n = x32_load(X1 + (size_t)nx.b * x1_bs + nx.p0, P, q, n, nx.ok), x2n = x32_load(X2 + (size_t)nx.b * x2_bs + nx.p0, P, q, n, nx.ok);
+  for (int g = wave0; g < ngroups; g += nwaves) {
+    const G32 at = nx;
+    const X32 x1 = x1n, x2 = x2n;
+    if (g + nwaves < ngroups) {
+      nx = g32_of(g + nwaves, gpp, P, n);
+      x1n = x32_load(X1 + (size_t)nx.b * x1_bs + nx.p0, P, q, n, nx.ok);
+      x2n = x32_load(X2 + (size_t)nx.b * x2_bs + nx.p0, P, q, n, nx.ok);
+    }
+    A32 acc;
+    a32_zero(acc);
+    a32_mma(acc, wa, x1);
+    a32_mma(acc, wb, x2);
+    a32_bias(acc, bias, q);
+    a32_store(acc, Y + (size_t)at.b * y_bs + at.p0, P, q, n, at.ok);
+  }
+}
+
+// Read-out of a hidden-32 network in one pass (model/ppgn.py:318-333): R = layer_cat_lin(cat([A, sigma I, u_1 .. u_L])),
+// act = LeakyReLU(after_conv(R)), logits = final_lin(R + act).  The L + 1 weight blocks of layer_cat_lin go through LDS ([k][33]
+// floats: the A-operand reads of 16 consecutive rows are conflict-free), after_conv / final_lin stay in registers; R and act never
+// leave the wave unless training asks for them (Rs / As, nullable).  logits [B][N][N]; ld = padded row length of the planes.
+constexpr int H32_MAXL = 16;
+__global__ __launch_bounds__(256) void head32w_kernel(const float* __restrict__ cat, long cat_bs, const float* __restrict__ Wc, int ldc, const float* __restrict__ bc,
+                                                      const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wf, const float* __restrict__ bf,
+                                                      float* __restrict__ Rs, float* __restrict__ As, long hs, float* __restrict__ logits, int N, int ld, int L, int B) {
+  extern __shared__ float wlds[];                            // [(2 + 32 L)][33]
+  const int P = N * ld, K = 2 + 32 * L;
+  for (int i = threadIdx.x; i < 32 * K; i += blockDim.x) { const int o = i / K, k = i - o * K; wlds[k * 33 + o] = Wc[(size_t)o * ldc + k]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int gpp = (P + 63) >> 6, ngroups = B * gpp;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
+  const W32 wac = w32_load(Wa, 32, q, n);
+  float wfin[2][4];
+#pragma unroll
+  for (int co = 0; co < 2; ++co)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wfin[co][r] = wf[16 * co + 4 * q + r];
+  const float bfin = bf[0];
+  for (int g = wave0; g < ngroups; g += nwaves) {
+    const G32 at = g32_of(g, gpp, P, n);
+    const float* cp = cat + (size_t)at.b * cat_bs + at.p0;
+    A32 R;
+    a32_zero(R);
+    {   // the two input planes: rank-2 update
+      const float4 a4 = at.ok ? *reinterpret_cast<const float4*>(cp + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 s4 = at.ok ? *reinterpret_cast<const float4*>(cp + P + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * co + 4 * q + r;
+          const float c0 = wlds[0 * 33 + o], c1 = wlds[1 * 33 + o];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) R.a[j][co][r] = c0 * f4_at(a4, j) + c1 * f4_at(s4, j);
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+      const X32 x = x32_load(cp + (size_t)(2 + 32 * l) * P, P, q, n, at.ok);
+      W32 w;
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int co = 0; co < 2; ++co) w.w[ci][r][co] = wlds[(2 + 32 * l + 16 * ci + 4 * q + r) * 33 + 16 * co + n];
+      a32_mma(R, w, x);
+    }
+    a32_bias(R, bc, q);
+    if (Rs) a32_store(R, Rs + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
+    A32 act;
+    a32_zero(act);
+    a32_mma_chain(act, wac, R);
+    a32_bias(act, ba, q);
+    a32_leaky(act);
+    if (As) a32_store(act, As + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
+    float part[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc += wfin[co][r] * (R.a[j][co][r] + act.a[j][co][r]);
+      sacc += __shfl_xor(sacc, 16, 64);
+      sacc += __shfl_xor(sacc, 32, 64);
+      part[j] = sacc + bfin;
+    }
+    if (q == 0 && at.ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = at.p0 + 4 * n + j, i = p / ld, jj = p - i * ld;
+        if (jj < N) logits[((size_t)at.b * N + i) * N + jj] = part[j];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------------------
 struct Ctx {
@@ -799,6 +1048,16 @@ GemmArgs base_args() {
   GemmArgs a{};
   a.nseg = 1; a.nsplit = 1; a.kchunk = 0; a.scale_div = 1; a.mul_div = 1;
   return a;
+}
+
+// the wide hidden-32 kernels apply: 16-byte aligned planes whose rows are multiples of four positions
+inline bool wide32_ok(int P, const float* x, long x_bs, const float* y, long y_bs) {
+  return sw(SW_DISABLE_WIDE32) == 0 && P % 4 == 0 && aligned16(x) && aligned16(y) && x_bs % 4 == 0 && y_bs % 4 == 0;
+}
+inline int wide32_grid(int B, int P) {   // persistent waves: four per block, up to 8 blocks per CU's worth of work in flight
+  const long groups = (long)B * ((P + 63) / 64);
+  const long blocks = (groups + 3) / 4;
+  return (int)(blocks < 2048 ? blocks : 2048);
 }
 
 // Y[b] (M x P) = epilogue( sum_s W_s (M x K_s) * X_s[b] (K_s x P) )
@@ -880,6 +1139,16 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
     return ws_mlp_forward(wa, save_hid, c.st);   // the saved hidden activations come from the exact-f32 kernel
   }
   const bool mlp32_off = sw(SW_DISABLE_MLP32) != 0;   // A/B switch for measurements
+  if (H == 32 && !mlp32_off && wide32_ok(c.P, x, x_bs, o1, hs) && aligned16(o2) && (!maskp || aligned16(maskp)) &&
+      (!save_hid || (aligned16(hid1) && aligned16(hid2)))) {   // 64 positions per wave, 16-byte accesses
+    const bool prof = prof_enabled();
+    if (prof) prof_before(c.st);
+    hipLaunchKernelGGL(mlp32w_fwd_kernel, dim3(wide32_grid(c.B, c.P)), dim3(256), 0, c.st, x, x_bs, (const float*)q.m1_w0, (const float*)q.m2_w0,
+                       (const float*)q.m1_w1, (const float*)q.m2_w1, (const float*)q.m1_b0, (const float*)q.m2_b0, (const float*)q.m1_b1, (const float*)q.m2_b1,
+                       maskp, o1, o2, save_hid ? hid1 : (float*)nullptr, save_hid ? hid2 : (float*)nullptr, hs, c.P, c.B);
+    if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 8.0 * 32 * 32 * (double)c.P * c.B, (save_hid ? 5.0 : 3.0) * sizeof(float) * 32 * (double)c.P * c.B);
+    return check_launch("mlp32w_fwd");
+  }
   if (H == 32 && !mlp32_off) {   // hidden-32 networks: both MLPs of the layer in one streaming launch
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
@@ -1187,6 +1456,13 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         }
         continue;
       }
+    } else if (H == 32 && wide32_ok(P, mm, hs, y, hs) && aligned16(x) && x_bs % 4 == 0) {
+      const bool prof = prof_enabled();
+      if (prof) prof_before(c.st);
+      hipLaunchKernelGGL(lin32x2w_kernel, dim3(wide32_grid(B, P)), dim3(256), 0, c.st, (const float*)q.m4_w, 2 * H, (const float*)q.m4_b, (const float*)mm, hs,
+                         x, x_bs, y, hs, P, B);
+      if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 4.0 * 32 * 32 * (double)P * B, 3.0 * sizeof(float) * 32 * (double)P * B);
+      DPPM_TRY(check_launch("lin32x2w"));
     } else {
       LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
@@ -1204,6 +1480,19 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     HeadArgs ha{cat, cat_bs, reinterpret_cast<const uint4*>(c.at(w.himg)), pr->cat_w, w.CT, pr->cat_b, pr->after_b, pr->final_w, pr->final_b,
                 logits, B, N, w.ld, P, L, fuse_norm ? naff : nullptr, fuse_norm ? maskp : nullptr};
     return head3_run(ha, pr->after_w, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
+  }
+  if (H == 32 && L <= H32_MAXL && wide32_ok(P, cat, cat_bs, c.at(w.R), hs) && aligned16(c.at(w.act))) {   // hidden-32 read-out in one pass
+    const size_t lds = (size_t)(2 + 32 * L) * 33 * sizeof(float);
+    DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&head32w_kernel), lds, "head32w"));
+    const bool prof = prof_enabled();
+    if (prof) prof_before(c.st);
+    const int grid = wide32_grid(B, P) < 512 ? wide32_grid(B, P) : 512;   // every block stages the weights once
+    hipLaunchKernelGGL(head32w_kernel, dim3(grid), dim3(256), lds, c.st, (const float*)cat, cat_bs, (const float*)pr->cat_w, w.CT, (const float*)pr->cat_b,
+                       (const float*)pr->after_w, (const float*)pr->after_b, (const float*)pr->final_w, (const float*)pr->final_b,
+                       training ? c.at(w.R) : (float*)nullptr, training ? c.at(w.act) : (float*)nullptr, hs, logits, N, w.ld, L, B);
+    if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 2.0 * 32 * ((double)w.CT + 32 + 1) * P * B,
+                         sizeof(float) * ((double)w.CT * P + (training ? 64.0 * P : 0.0) + (double)N * N) * B);
+    return check_launch("head32w");
   }
   // layer_cat_lin over cat([A, sigma I, u_1..u_L])   (model/ppgn.py:318,327)
   if (use_wstat(H)) {   // K = 2 + L*128: the layer outputs two at a time through the weight-stationary kernel, [A, sigma I] as a side input

@@ -12,6 +12,14 @@
 namespace dppm {
 
 constexpr int W4_THREADS = 1024;
+#ifndef W4_HALF
+#define W4_HALF 0
+#endif
+// Timing ablations, compile time only (-DW4_ABLATE=bits; results are wrong on purpose): 1 no output stores, 2 no second-product MFMAs,
+// 4 no first-product MFMAs, 8 the stagers request no new tiles (tools/dbg/mlp_ablate.sh)
+#ifndef W4_ABLATE
+#define W4_ABLATE 0
+#endif
 // Timing instrument, compiled in with -DW4_TRACE_ON=1 only: with DPPM_DBG_W4=2048 workgroup 8 of w4_mlp_kernel records, per barrier
 // interval, the 100 MHz wall clock at which one wave of each role (0 stager, 1 first product, 2 second product) leaves the barrier
 // (k = 0), reaches the next one (k = 1) and ends its MFMA loop (k = 2); the 21st launch writes gpurun_out/w4_trace.txt.
@@ -25,6 +33,15 @@ __device__ unsigned long long g_w4_trace[3 * 3 * 256];
 #define W4_TRACE(role, i, k) do { } while (0)
 #endif
 
+// Staging thread t -> (position quad q, channel group cg) of the role-split kernels.  The 16 lanes of a ds_write_b64 group are
+// served in one LDS cycle only if they cover 16 distinct 8-byte bank pairs of the 128-byte store row.  An image slot is (8-byte half
+// cg & 1) of (16-byte chunk (cg >> 1) ^ 4 (q & 3) ^ (q >> 2) ^ e): with the plain map (q = t & 15, cg = t >> 4) the 16 lanes share cg,
+// sit on one half and reach 8 chunks twice -- two cycles per group, a quarter of w4_mlp_kernel's LDS cycles (SQ_LDS_BANK_CONFLICT,
+// profiles/r02f_pmc_mfma_lds.txt).  Here lane bit 0 is cg's low bit and q's bit 1 (which the chunk's low three bits do not see) is
+// lane bit 4: 2 halves x 8 chunks.  A wave still covers four channel rows x 256 contiguous bytes per global load instruction.
+// (Measured: the conflict cycles go, the launch time does not move -- the stores' LDS cycles were never on the critical path.)
+__device__ __forceinline__ unsigned w4_q(int t) { return ((t >> 1) & 1) | (((t >> 4) & 1) << 1) | (((t >> 2) & 3) << 2); }
+__device__ __forceinline__ unsigned w4_cg(int t) { return (t & 1) | ((t >> 5) << 1); }
 struct W4Pre { float4 a, b, c, d, sc, sh; float m; };   // one tile in flight per staging thread (named members: registers)
 
 // w3_mma4 with the LDS fragment reads one (k step, position group) ahead of the MFMAs that use them: a multiplying wave shares its
@@ -82,14 +99,45 @@ __device__ __forceinline__ void w4_mma8(floatx4 (&acc)[2][4], const uintx4 (&wh)
   }
 }
 
+// w4_mma8 over the position groups J0 .. J0 + NJ - 1 only, with a hook after every k step: `between(n)` is program text that the
+// scheduler may not move (sched_barrier on both sides), i.e. vector work of ANOTHER half tile issued in the shadow of these MFMAs.
+template <int NS, bool W_IS_A, int J0, int NJ, typename F>
+__device__ __forceinline__ void w4_mma8_part(floatx4 (&acc)[2][4], const uintx4 (&wh)[2][4], const uintx4 (&wl)[2][4], const char* __restrict__ T, const W3Addr& ad,
+                                             F&& between) {
+  uintx4 xh[2], xl[2];
+  xh[0] = *reinterpret_cast<const uintx4*>(T + w3_off(ad, J0, 0));
+  xl[0] = xh[0];
+  if (NS > 1) xl[0] = *reinterpret_cast<const uintx4*>(T + W3_IMG + w3_off(ad, J0, 0));
+#pragma unroll
+  for (int n = 0; n < 4 * NJ; ++n) {
+    const int s = n / NJ, j = J0 + n % NJ, cur = n & 1, nxt = cur ^ 1;
+    if (n + 1 < 4 * NJ) {
+      const unsigned off = w3_off(ad, J0 + (n + 1) % NJ, (n + 1) / NJ);
+      xh[nxt] = *reinterpret_cast<const uintx4*>(T + off);
+      if (NS > 1) xl[nxt] = *reinterpret_cast<const uintx4*>(T + W3_IMG + off); else xl[nxt] = xh[nxt];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      if (NS > 1) {
+        acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], xl[cur], acc[cb][j]) : w3_mfma(xl[cur], wh[cb][s], acc[cb][j]);
+        acc[cb][j] = W_IS_A ? w3_mfma(wl[cb][s], xh[cur], acc[cb][j]) : w3_mfma(xh[cur], wl[cb][s], acc[cb][j]);
+      }
+      acc[cb][j] = W_IS_A ? w3_mfma(wh[cb][s], xh[cur], acc[cb][j]) : w3_mfma(xh[cur], wh[cb][s], acc[cb][j]);
+    }
+    between(n);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // in_lin while staging (WsArgs::inl_*): the staging thread's four channels 4 cg .. 4 cg + 3 at its four positions from the two
 // input values of each position
 struct W4Inl { float w0[4], w1[4], b[4]; };
-__device__ __forceinline__ W4Inl w4_inl_load(const WsArgs& a, int tid) {
+__device__ __forceinline__ W4Inl w4_inl_load(const WsArgs& a, int cg) {
   W4Inl r;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    const int c = 4 * (tid >> 4) + v;
+    const int c = 4 * cg + v;
     r.w0[v] = a.inl_w[2 * c]; r.w1[v] = a.inl_w[2 * c + 1]; r.b[v] = a.inl_b ? a.inl_b[c] : 0.f;
   }
   return r;
@@ -139,11 +187,12 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
 
   if (role == 0) {
     // ------------------------------------------------------------------------------------------------ stagers
-    const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);   // channels 4 cg .., positions 4 q ..
-    const int oc = 4 * (tid & 15);
+    const unsigned sq = w4_q(tid), scg = w4_cg(tid);
+    const unsigned o0 = (4 * scg) * P + 4 * sq;              // channels 4 cg .., positions 4 q ..
+    const int oc = 4 * sq;
     int qi = 0, qs = 0;                                      // issue cursor (tile, source)
     W4Inl inl{};
-    if (INLIN) inl = w4_inl_load(a, tid);
+    if (INLIN) inl = w4_inl_load(a, scg);
     auto issue = [&](W4Pre& pre) {                           // unconditional clamped loads of the tile at the cursor
       const int t = rank + (qi < nloc ? qi : nloc - 1) * G;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
@@ -160,7 +209,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
       pre.c = *reinterpret_cast<const float4*>(Xt + s2);
       pre.d = *reinterpret_cast<const float4*>(Xt + s3);
       if (NRM) {
-        const float* T = a.aff + (size_t)b * 256 + 4 * (tid >> 4);
+        const float* T = a.aff + (size_t)b * 256 + 4 * scg;
         pre.sc = *reinterpret_cast<const float4*>(T);
         pre.sh = *reinterpret_cast<const float4*>(T + 128);
         pre.m = a.maskstat[(size_t)b * P + ((p0 + lane < P) ? p0 + lane : 0)];
@@ -181,7 +230,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
       } else if (NRM && ls == 1) {                           // the skip input's instance norm (uniform branch)
         w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w);
       }
-      w3_tile_store4<NS>(xa, xb, xc, xd, Xs + buf * BUF, tid);
+      w3_tile_store4_qc<NS>(xa, xb, xc, xd, Xs + buf * BUF, sq, scg);
       if (NRM && ls == 0 && tid < 64) Ms[(li & 1) * 64 + tid] = (li < nloc && p0 + lane < P) ? pre.m : 0.f;
       if (++ls == 2) { ls = 0; ++li; }
     };
@@ -289,11 +338,12 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   if (wave < STG) {
     // ------------------------------------------------------------------------------------------------ stagers
     using Pre = W4PreT<NQ>;
-    const unsigned o0 = (unsigned)(4 * (tid >> 4)) * P + 4 * (tid & 15);
-    const int oc = 4 * (tid & 15);
+    const unsigned sq = w4_q(tid), scg = w4_cg(tid);
+    const unsigned o0 = (4 * scg) * P + 4 * sq;
+    const int oc = 4 * sq;
     int qi = 0;
     W4Inl inl{}, inl2{};
-    if (INLIN) { inl = w4_inl_load(a, tid); if (NQ == 2) inl2 = w4_inl_load(a, tid + 256); }
+    if (INLIN) { inl = w4_inl_load(a, scg); if (NQ == 2) inl2 = w4_inl_load(a, scg + 16); }
     auto issue = [&](Pre& pre) {
       const int t = who.rank + (qi < nloc ? qi : nloc - 1) * who.per_job;
       const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
@@ -328,7 +378,7 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
       const int b = t / tpp, p0 = (t - b * tpp) * WS_TP;
       // No zero fill: positions past the plane's end and landings past the last tile hold clamped duplicates that no store uses.
       char* Xb = Xs + (li & 1) * BUF;
-      const float* Ab = As + (li & 1) * 256 + 4 * (tid >> 4);
+      const float* Ab = As + (li & 1) * 256 + 4 * scg;
       {
         float4 xa, xb, xc, xd;
         if (INLIN) {
@@ -340,9 +390,9 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
           const float4 sc = *reinterpret_cast<const float4*>(Ab), sh = *reinterpret_cast<const float4*>(Ab + 128);
           w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
         }
-        w3_tile_store4<NS>(xa, xb, xc, xd, Xb, tid);
+        w3_tile_store4_qc<NS>(xa, xb, xc, xd, Xb, sq, scg);
       }
-      if constexpr (NQ == 2) {                               // channels 64 + 4 cg ..: the image slots of "thread tid + 256"
+      if constexpr (NQ == 2) {                               // channels 64 + 4 cg ..: channel group cg + 16
         float4 xa, xb, xc, xd;
         if constexpr (INLIN) {
           xa = w4_inl_row(inl2, 0, pre.a, pre.b); xb = w4_inl_row(inl2, 1, pre.a, pre.b); xc = w4_inl_row(inl2, 2, pre.a, pre.b); xd = w4_inl_row(inl2, 3, pre.a, pre.b);
@@ -353,7 +403,7 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
           const float4 sc = *reinterpret_cast<const float4*>(Ab + 64), sh = *reinterpret_cast<const float4*>(Ab + 192);
           w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
         }
-        w3_tile_store4<NS>(xa, xb, xc, xd, Xb, tid + 256);
+        w3_tile_store4_qc<NS>(xa, xb, xc, xd, Xb, sq, scg + 16);
       }
       if (tid < 64) {
         Ms[(li & 3) * 64 + tid] = (maskp && li < nloc && p0 + lane < P) ? pre.m : (maskp ? 0.f : 1.f);
@@ -376,6 +426,7 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
       for (int u = 0; u < 3; ++u) {
         if (q + u <= nloc) {
           if (wave == 0) W4_TRACE(0, q + u, 0);
+          if (W4_ABLATE & 8) { if (u == 0) land(p1s); else if (u == 1) land(p2s); else land(p0s); } else
           if (u == 0) { issue(p0s); land(p1s); }
           else if (u == 1) { issue(p1s); land(p2s); }
           else { issue(p2s); land(p0s); }
@@ -417,22 +468,37 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // bias, LeakyReLU, split and the hidden-image stores of one (channel block, position group) unit
+        auto h_unit = [&](int cb, int j) {
+          const float4 b1 = b1w[cb];
+          const unsigned hchunk = (unsigned)(2 * (2 * pw + cb) + (g >> 1)) ^ (unsigned)ci;
+          unsigned h01, l01 = 0, h23, l23 = 0;
+          w3_split2<NS>(ws_leaky(acc[cb][j][0] + b1.x), ws_leaky(acc[cb][j][1] + b1.y), h01, l01);
+          w3_split2<NS>(ws_leaky(acc[cb][j][2] + b1.z), ws_leaky(acc[cb][j][3] + b1.w), h23, l23);
+          const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
+          *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
+          if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
+        };
+#if W4_HALF
+        // Two half tiles: the vector work of positions 0 .. 31 is issued between the MFMAs of positions 32 .. 63 (one unit per two k
+        // steps), so that only the second half's epilogue is exposed behind the wave's last MFMA.
+        const char* Xb = Xs + (i & 1) * BUF;
+        if (!(W4_ABLATE & 4))
+        {
+        w4_mma8_part<NS, true, 0, 2>(acc, wh, wl, Xb, ad, [](int) {});
+        w4_mma8_part<NS, true, 2, 2>(acc, wh, wl, Xb, ad, [&](int n) { if (n & 1) h_unit((n >> 1) & 1, n >> 2); });
+        }
+        if (pw == 0) W4_TRACE(1, i, 2);
+#pragma unroll
+        for (int j = 2; j < 4; ++j) { h_unit(0, j); h_unit(1, j); }
+#else
         w4_mma8<NS, true>(acc, wh, wl, Xs + (i & 1) * BUF, ad);
         if (pw == 0) W4_TRACE(1, i, 2);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          const float4 b1 = b1w[cb];
-          const unsigned hchunk = (unsigned)(2 * (2 * pw + cb) + (g >> 1)) ^ (unsigned)ci;
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            unsigned h01, l01 = 0, h23, l23 = 0;
-            w3_split2<NS>(ws_leaky(acc[cb][j][0] + b1.x), ws_leaky(acc[cb][j][1] + b1.y), h01, l01);
-            w3_split2<NS>(ws_leaky(acc[cb][j][2] + b1.z), ws_leaky(acc[cb][j][3] + b1.w), h23, l23);
-            const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
-            *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
-            if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);
-          }
-        }
+          for (int j = 0; j < 4; ++j) h_unit(cb, j);
+#endif
       }
       if (pw == 0) W4_TRACE(1, i, 1);
       __syncthreads();
@@ -447,7 +513,8 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   // by 3.0 us; stagers done at 2.6 us.  The groups wait for each other's vector and LDS instructions more than for the matrix pipe.
   // Skewing this group against the first product's waves on the same SIMDs -- the stores of tile i-2 at the START of interval i,
   // accumulators kept over the barrier -- was slower (0.56 against 0.535 ms: that epilogue then takes 2.1 us beside the other
-  // group's MFMAs); s_setprio for either role changed nothing; both channel blocks through the patch behind ONE wait (block 1 written as
+  // group's MFMAs; repeated in round 3 with the packed-f32 operations taken out of the epilogue, -fno-slp-vectorize: 0.523 against
+  // 0.494 ms); s_setprio for either role changed nothing; both channel blocks through the patch behind ONE wait (block 1 written as
   // soon as block 0's reads are issued, eight stores in a row) was slower too: 0.549 against 0.515 ms.
   float b2v[2];
 #pragma unroll
@@ -463,12 +530,13 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (!(W4_ABLATE & 2))
       w4_mma8<NS, false>(acc, wh, wl, Hs + ((i - 1) & 1) * BUF, ad);
       if (pw == 0) W4_TRACE(2, i, 2);
       const float* Mb = Ms + ((i - 1) & 3) * 64;
       float* Yt = J.Y + (size_t)b * J.y_bs + p0;
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) ws_store_wide_lds(acc[cb], Rw, Yt, 32 * pw + 16 * cb, P, b2v[cb], Mb, P - p0, lane);
+      for (int cb = 0; cb < 2; ++cb) ws_store_wide_lds(acc[cb], Rw, Yt, 32 * pw + 16 * cb, P, b2v[cb], Mb, (W4_ABLATE & 1) ? 0 : P - p0, lane);
     }
     if (pw == 0) W4_TRACE(2, i, 1);
     __syncthreads();

@@ -93,15 +93,19 @@ __device__ __forceinline__ void w3_put4(char* __restrict__ T, unsigned off, floa
   *reinterpret_cast<uint2*>(T + off) = make_uint2(h01, h23);
   if (NS > 1) *reinterpret_cast<uint2*>(T + W3_IMG + off) = make_uint2(l01, l23);
 }
+// thread (q, cg): channels 4 cg .. 4 cg + 3 of positions 4 q .. 4 q + 3
 template <int NS>
-__device__ __forceinline__ void w3_tile_store4(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, int tid) {
-  const unsigned q = tid & 15, cg = tid >> 4;
+__device__ __forceinline__ void w3_tile_store4_qc(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, unsigned q, unsigned cg) {
   const unsigned base = (4 * q) * 256 + (cg & 1) * 8;
   const unsigned kc = (cg >> 1) ^ (4 * (q & 3)) ^ (q >> 2);   // swizzled chunk of position 4q; position 4q + e: kc ^ e
   w3_put4<NS>(T, base + ((kc ^ 0) << 4), r0.x, r1.x, r2.x, r3.x);
   w3_put4<NS>(T, base + 256 + ((kc ^ 1) << 4), r0.y, r1.y, r2.y, r3.y);
   w3_put4<NS>(T, base + 512 + ((kc ^ 2) << 4), r0.z, r1.z, r2.z, r3.z);
   w3_put4<NS>(T, base + 768 + ((kc ^ 3) << 4), r0.w, r1.w, r2.w, r3.w);
+}
+template <int NS>
+__device__ __forceinline__ void w3_tile_store4(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, int tid) {
+  w3_tile_store4_qc<NS>(r0, r1, r2, r3, T, tid & 15, tid >> 4);
 }
 template <int NS>
 __device__ __forceinline__ void w3_tile_store(const float4 (&r)[4], char* __restrict__ T, int tid) {

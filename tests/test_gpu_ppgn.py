@@ -77,6 +77,37 @@ def test_forward_backward_golden(ops, tag):
     close(lb, g["logits_batched_sigma0"])
 
 
+@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (2, 200, 6), (5, 64, 2), (1, 23, 16)])
+def test_hidden32_wide_kernels(ops, B, N, L):
+    """Hidden-32 networks at N > 20 (SURVEY 8 C4 "also 6 x 32", gridsearch_ppgn_simple.py:19): the wide kernels (64 positions per wave,
+    16-byte accesses: both MLPs of a layer, m4 on cat(mm, x), the whole read-out in one pass; dppm_ppgn.hip) against the oracle and
+    against the 16-position / generic-GEMM forms they replace (DISABLE_WIDE32), inference and training forward + gradients.  N = 41 and
+    23: padded rows (ld > N) and a last group that ends inside its 64 positions; L = 16: the largest read-out the kernel stages."""
+    from oracle import ppgn as op
+    H = 32
+    rng = np.random.default_rng(6100 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 13 * L)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H)
+    with ops.debug_switch(DISABLE_WIDE32=1):
+        old, _ = run_gpu(ops, W, A, mask, sigma, L, H)
+    close(got, ref)
+    close(got, old, tol=2e-5)
+    assert not np.array_equal(got, old) or N < 8      # the switch did select other kernels (different summation order)
+    R = rng.normal(size=A.shape).astype(np.float32) * mask
+    lg, g = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
+    with ops.debug_switch(DISABLE_WIDE32=1):
+        lg0, g0 = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
+    close(lg, lg0, tol=2e-5)
+    gmax = max(np.abs(v).max() for v in g0.values())
+    for k in g0:
+        # (both forms sit ~1e-3 from float64 at N = 200, L = 6: LeakyReLU kink flips, tools/dbg/h32_grads.py; the bar of the gradient tests)
+        assert np.abs(g[k] - g0[k]).max() <= 3e-3 * max(np.abs(g0[k]).max(), 2e-2 * gmax), k
+
+
 @pytest.mark.parametrize("B,N,H,L", [(2, 20, 32, 2), (3, 33, 16, 2), (1, 12, 128, 2), (1, 129, 32, 1), (2, 8, 64, 3)])
 def test_forward_backward_vs_oracle(ops, B, N, H, L):
     from oracle import ppgn as op
