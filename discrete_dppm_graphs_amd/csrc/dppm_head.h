@@ -18,7 +18,8 @@
 
 namespace dppm {
 
-constexpr int HD_THREADS = 1024;             // 8 staging waves + 8 multiplying waves, one workgroup per CU
+constexpr int HD_STG = 4;                     // staging waves
+constexpr int HD_THREADS = 64 * (HD_STG + 8); // 4 staging waves + 8 multiplying waves (168 registers each), one workgroup per CU
 #ifndef HD_NT_VAL
 #define HD_NT_VAL 2
 #endif

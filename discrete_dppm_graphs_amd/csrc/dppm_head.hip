@@ -22,7 +22,10 @@ __global__ __launch_bounds__(512) void head_wimg_kernel(const float* __restrict_
   }
 }
 
-struct HdPre { float4 a, b, c, d, sc, sh; };    // one X tile in flight per thread (named members: stays in registers); sc / sh: NRM only
+// one X tile in flight per staging thread (named members: stays in registers): channel groups cg (a .. d) and cg + 16 (e .. h);
+// t: float `tid` of the NEXT tile's 256-float (scale, shift) table (NRM); s: the epilogue's per-position input of staging wave k at
+// position p0 + lane -- k = 0: A, 1: sigma I, 2: the mask (3: unused) -- written to LDS when the tile belongs to source 0
+struct HdPre { float4 a, b, c, d, e, f, g, h; float t, s; };
 struct HdW { uintx4 h[4], l[4]; };              // a wave's fragments of one weight phase
 
 template <int NS>
@@ -74,11 +77,16 @@ __device__ __forceinline__ void hd_mma4_reload(floatx4 (&acc)[4], HdW& W, const 
   }
 }
 
-// Roles: waves 0-7 stage (global -> registers -> bf16 images in LDS; up to four tiles in flight per thread, no accumulators),
-// waves 8-15 multiply (weight fragments + accumulators, LDS reads and MFMAs only) and run the epilogue.  Every wave executes
-// the same sequence of barriers: one per X tile, HD_NT + 1 per epilogue.
+// Roles: waves 0 .. 3 stage (global -> registers -> bf16 images in LDS; three tiles in flight per thread, two channel groups each,
+// no accumulators), waves 4 .. 11 multiply (weight fragments + accumulators, LDS reads and MFMAs only) and run the epilogue:
+// 12 waves at 168 registers (round 2's 8 + 8 waves at 128 registers spilled 36 / 39 registers in the multiplying waves).  Every wave
+// executes the same sequence of barriers: one per X tile, HD_NT + 1 per epilogue.
 // NRM: the layer outputs in CAT are the RAW m4 results; their masked instance norm (a.aff: [L][B][2][128] scale, shift) is applied
 // while staging, and the mask (a.maskp) when the accumulators are finished (a masked u_l is an exact zero: model/ppgn.py:315).
+// The (scale, shift) table of a tile's (source, graph) goes through LDS as in w4_mlp_kernel: with tile q the stagers request one
+// float4 of tile q+1's table (pre.t), write it to As[(q+1) & 1] when tile q lands and read their channels' pairs one barrier later.
+// The epilogue's per-position inputs (A, sigma I, mask) travel the same way: requested with every tile, written to Ss by the
+// first staging wave when a tile of source 0 lands, read by the multiplying waves in that super-tile's epilogue.
 template <int NS, bool NRM>
 __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_hd[];
@@ -88,9 +96,11 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   char* Hs = smem_hd + 2 * BUF;                              // [2][BUF] R tile images (epilogue)
   float* Cs = reinterpret_cast<float*>(smem_hd + 4 * BUF);   // [5][128]: cat_w[:,0], cat_w[:,1], cat_b, after_b, final_w
   float* Ls = Cs + 5 * WS_H;                                 // [2][8 waves][64] partial logits
+  float* Ss = Ls + 2 * 8 * WS_TP;                            // [2 super-tile parities][HD_NT][3][64]: A, sigma I, mask rows of the super-tile's tiles
+  float* As = Ss + 2 * HD_NT * 3 * WS_TP;                    // [2 tile parities][256]: (scale, shift) tables (NRM)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 3, w = wave & 7;                  // role 0: stager, role 1: multiplier of channels 16 w ..
+  const int w = wave - HD_STG;                               // < 0: stager, else multiplier of channels 16 w ..
   const int g = lane >> 4, ci = lane & 15;
   const int P = a.P, L = a.L;
   const int nsp = (P + HD_SP - 1) / HD_SP;                   // super-tiles per graph
@@ -106,6 +116,8 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
     Cs[3 * WS_H + tid] = a.after_b[tid];
     Cs[4 * WS_H + tid] = a.final_w[tid];
   }
+  if (NRM && tid < 64)                                       // tile 0's table, directly (source 0, the graph of super-tile `rank`)
+    *reinterpret_cast<float4*>(As + 4 * tid) = *reinterpret_cast<const float4*>(a.aff + (size_t)(rank / nsp) * 256 + 4 * tid);
   const float fbias = a.final_b[0];
   const int per_sp = L * HD_NT;                              // X tiles per super-tile
   const int nq = nloc * per_sp;                              // X tiles of this workgroup, in stream order q = (i * L + s) * HD_NT + t
@@ -120,11 +132,11 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
     if (p < P && col < a.N) a.logits[((size_t)b * a.N + row) * a.N + col] = v;
   };
 
-  if (role == 0) {
+  if (w < 0) {
     // ------------------------------------------------------------------------------------------------ stagers
-    const int u512 = tid;                                    // 0 .. 511
-    const unsigned o0 = (unsigned)(4 * (u512 >> 4)) * P + 4 * (u512 & 15);   // channels 4 cg .., positions 4 q ..
-    const int oc = 4 * (u512 & 15);
+    const unsigned sq = w4_q(tid), scg = w4_cg(tid);         // position quad 0 .. 15, channel groups scg and scg + 16
+    const unsigned o0 = (4 * scg) * P + 4 * sq;
+    const int oc = 4 * sq;
     int qi = 0, qs = 0, qt = 0;                              // issue cursor
     auto issue = [&](HdPre& pre) {                           // unconditional clamped loads of the tile at the cursor
       const int ii = qi < nloc ? qi : nloc - 1;
@@ -137,27 +149,51 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       pre.b = *reinterpret_cast<const float4*>(Xt + (size_t)P);
       pre.c = *reinterpret_cast<const float4*>(Xt + (size_t)2 * P);
       pre.d = *reinterpret_cast<const float4*>(Xt + (size_t)3 * P);
-      if (NRM) {
-        const float* T = a.aff + ((size_t)qs * a.B + b) * 256 + 4 * (u512 >> 4);
-        pre.sc = *reinterpret_cast<const float4*>(T);
-        pre.sh = *reinterpret_cast<const float4*>(T + 128);
+      const float* Xu = Xt + (size_t)64 * P;
+      pre.e = *reinterpret_cast<const float4*>(Xu);
+      pre.f = *reinterpret_cast<const float4*>(Xu + (size_t)P);
+      pre.g = *reinterpret_cast<const float4*>(Xu + (size_t)2 * P);
+      pre.h = *reinterpret_cast<const float4*>(Xu + (size_t)3 * P);
+      {   // the epilogue's side inputs travel with the stream (every tile, unconditionally: the counted waits stay exact)
+        const int ps = p0 + lane < P ? p0 + lane : 0;
+        const float* Sd = (NRM && wave == 2) ? a.maskp + (size_t)b * P : a.cat + (size_t)b * a.cat_bs + (wave == 1 ? (size_t)P : (size_t)0);   // (uniform)
+        pre.s = Sd[ps];
       }
       if (++qt == HD_NT) { qt = 0; if (++qs == L) { qs = 0; ++qi; } }
+      if (NRM) {                                             // the cursor now names the NEXT tile: its (source, graph) table
+        const int b1 = __builtin_amdgcn_readfirstlane((rank + (qi < nloc ? qi : nloc - 1) * G) / nsp);
+        pre.t = a.aff[((size_t)qs * a.B + b1) * 256 + tid];
+      }
     };
-    int li = 0, ls = 0, lt = 0;                              // landing cursor
+    int li = 0, ls = 0, lt = 0, lq = 0;                      // landing cursor, and the tile's number in the stream
     auto land = [&](const HdPre& pre, int buf) {
-      const int ii = li < nloc ? li : nloc - 1;
-      const int st = rank + ii * G;
-      const int b = st / nsp;
-      const int p0 = (st - b * nsp) * HD_SP + WS_TP * lt;
-      const bool in = li < nloc && p0 + oc < P;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 xa = in ? pre.a : z, xb = in ? pre.b : z, xc = in ? pre.c : z, xd = in ? pre.d : z;
-      if (NRM) { w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w); }
-      w3_tile_store4<NS>(xa, xb, xc, xd, Xs + buf * BUF, u512);
+      // No zero fill: positions past the plane's end and landings past the last tile hold clamped duplicates.  A position is a column
+      // of D = W X -- no lane of another position reads it -- and flush() stores in-range positions only.
+      char* Xb = Xs + buf * BUF;
+      const float* Ab = As + (lq & 1) * 256 + 4 * scg;
+      {
+        float4 xa = pre.a, xb = pre.b, xc = pre.c, xd = pre.d;
+        if (NRM) {
+          const float4 sc = *reinterpret_cast<const float4*>(Ab), sh = *reinterpret_cast<const float4*>(Ab + 128);
+          w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
+        }
+        w3_tile_store4_qc<NS>(xa, xb, xc, xd, Xb, sq, scg);
+      }
+      {
+        float4 xa = pre.e, xb = pre.f, xc = pre.g, xd = pre.h;
+        if (NRM) {
+          const float4 sc = *reinterpret_cast<const float4*>(Ab + 64), sh = *reinterpret_cast<const float4*>(Ab + 192);
+          w3_affine(xa, sc.x, sh.x); w3_affine(xb, sc.y, sh.y); w3_affine(xc, sc.z, sh.z); w3_affine(xd, sc.w, sh.w);
+        }
+        w3_tile_store4_qc<NS>(xa, xb, xc, xd, Xb, sq, scg + 16);
+      }
+      if (NRM) As[((lq + 1) & 1) * 256 + tid] = pre.t;
+      if (ls == 0 && wave < 3) Ss[((li & 1) * HD_NT + lt) * 3 * WS_TP + tid] = pre.s;   // (uniform) rows A, sigma I, mask (NRM; else unused)
+      ++lq;
       if (++lt == HD_NT) { lt = 0; if (++ls == L) { ls = 0; ++li; } }
     };
     HdPre p0s, p1s, p2s;                                     // tile k travels in set k % 3, lands in X buffer k & 1
+    if (NRM) __syncthreads();                                // tile 0's table is in As[0]
     issue(p0s); issue(p1s); issue(p2s);
     land(p0s, 0);
     __syncthreads();                                         // tile 0 is in X buffer 0
@@ -198,6 +234,7 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   floatx4 acc[HD_NT][4];
   HdW W;
   hd_load_w<NS>(W, wbase);                                   // phase 0 of the first super-tile
+  if (NRM) __syncthreads();                                  // (the stagers' table of tile 0)
   __syncthreads();                                           // tile 0 is in X buffer 0
   for (int i = 0; i < nloc; ++i) {
 #pragma unroll
@@ -217,7 +254,6 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
     const int st = rank + i * G;
     const int b = __builtin_amdgcn_readfirstlane(st / nsp);
     const int sp0 = __builtin_amdgcn_readfirstlane((st - b * nsp) * HD_SP);
-    const float* side = a.cat + (size_t)b * a.cat_bs;
     const int c4 = 16 * w + 4 * g;                           // the lane's channels c4 .. c4 + 3
 #pragma unroll
     for (int t = 0; t < HD_NT; ++t) {
@@ -225,21 +261,14 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
       {
         const float4 ws0 = *reinterpret_cast<const float4*>(Cs + c4), ws1 = *reinterpret_cast<const float4*>(Cs + WS_H + c4);
         const float4 cb = *reinterpret_cast<const float4*>(Cs + 2 * WS_H + c4);
-        // The side values (and NRM: the mask) of the four position groups are requested together and waited for with an explicit
-        // vmcnt(0).  This wave also reloads spilled registers from scratch in here, and with only the compiler's counted waits
-        // (vmcnt(6), (5), (3), (1) over that mix of scratch and global loads) about one NRM forward in 15 at N = 200, B = 32 came
-        // out with 4-6 logits of ONE position group of ONE odd tile 5e-4 .. 6e-3 off, every workspace region before the logits
-        // being bit-identical (tools/dbg/head_race.py, ws_diff.py): as if a side / mask value had been used before its load had
-        // landed.  Built with -mllvm -amdgpu-waitcnt-forcezero, or with this wait: none in 150 forwards.
+        // The side values (and NRM: the mask) of the tile come from LDS, where the stagers left them with source 0 of this super-tile
+        // (Ss, by super-tile parity: the next super-tile's rows land before this epilogue).  Round 2 loaded them here from global memory
+        // next to reloads of spilled registers and needed an explicit vmcnt(0) to be deterministic; the multiplying waves now issue no
+        // vector-memory load in the epilogue besides the weight fragments of the next phase.
+        const float* Sr = Ss + ((i & 1) * HD_NT + t) * 3 * WS_TP + ci;
         float av4[4], sv4[4], mk4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int p = sp0 + WS_TP * t + 16 * j + ci;
-          const int pc = p < P ? p : 0;
-          av4[j] = side[pc]; sv4[j] = side[(size_t)P + pc];
-          mk4[j] = NRM ? a.maskp[(size_t)b * P + pc] : 1.f;
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt and lgkmcnt untouched
+        for (int j = 0; j < 4; ++j) { av4[j] = Sr[16 * j]; sv4[j] = Sr[WS_TP + 16 * j]; mk4[j] = NRM ? Sr[2 * WS_TP + 16 * j] : 1.f; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                        // R = acc + side input + bias -> registers and hidden image
           const float av = av4[j], sv = sv4[j];
@@ -247,8 +276,9 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
           if (NRM) {
             if (!(mk4[j] > 0.f)) r = floatx4{0.f, 0.f, 0.f, 0.f};
           }
-          r[0] += ws0.x * av + ws1.x * sv + cb.x; r[1] += ws0.y * av + ws1.y * sv + cb.y;
-          r[2] += ws0.z * av + ws1.z * sv + cb.z; r[3] += ws0.w * av + ws1.w * sv + cb.w;
+          // (w3_side_s: the compiler's packed form of this term, with crossed operand halves, is what made the kernel nondeterministic)
+          r[0] += w3_side_s(ws0.x, ws1.x, cb.x, av, sv); r[1] += w3_side_s(ws0.y, ws1.y, cb.y, av, sv);
+          r[2] += w3_side_s(ws0.z, ws1.z, cb.z, av, sv); r[3] += w3_side_s(ws0.w, ws1.w, cb.w, av, sv);
           unsigned h01, l01 = 0, h23, l23 = 0;
           w3_split2<NS>(r[0], r[1], h01, l01);
           w3_split2<NS>(r[2], r[3], h23, l23);
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(HD_THREADS) void head3_kernel(const HeadArgs a) {
   }
 }
 
-template <int NS> inline size_t head3_lds() { return (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + 5 * WS_H * sizeof(float) + 2 * 8 * WS_TP * sizeof(float); }
+template <int NS> inline size_t head3_lds() { return (size_t)4 * (NS > 1 ? 2 : 1) * W3_IMG + (5 * WS_H + 2 * 8 * WS_TP + 2 * HD_NT * 3 * WS_TP + 2 * 256) * sizeof(float); }
 
 template <int NS>
 static int head3_launch(const HeadArgs& a, const float* after_w, hipStream_t st) {

@@ -33,15 +33,7 @@ __device__ unsigned long long g_w4_trace[3 * 3 * 256];
 #define W4_TRACE(role, i, k) do { } while (0)
 #endif
 
-// Staging thread t -> (position quad q, channel group cg) of the role-split kernels.  The 16 lanes of a ds_write_b64 group are
-// served in one LDS cycle only if they cover 16 distinct 8-byte bank pairs of the 128-byte store row.  An image slot is (8-byte half
-// cg & 1) of (16-byte chunk (cg >> 1) ^ 4 (q & 3) ^ (q >> 2) ^ e): with the plain map (q = t & 15, cg = t >> 4) the 16 lanes share cg,
-// sit on one half and reach 8 chunks twice -- two cycles per group, a quarter of w4_mlp_kernel's LDS cycles (SQ_LDS_BANK_CONFLICT,
-// profiles/r02f_pmc_mfma_lds.txt).  Here lane bit 0 is cg's low bit and q's bit 1 (which the chunk's low three bits do not see) is
-// lane bit 4: 2 halves x 8 chunks.  A wave still covers four channel rows x 256 contiguous bytes per global load instruction.
-// (Measured: the conflict cycles go, the launch time does not move -- the stores' LDS cycles were never on the critical path.)
-__device__ __forceinline__ unsigned w4_q(int t) { return ((t >> 1) & 1) | (((t >> 4) & 1) << 1) | (((t >> 2) & 3) << 2); }
-__device__ __forceinline__ unsigned w4_cg(int t) { return (t & 1) | ((t >> 5) << 1); }
+// (stager thread map w4_q / w4_cg: dppm_wsplit.h)
 struct W4Pre { float4 a, b, c, d, sc, sh; float m; };   // one tile in flight per staging thread (named members: registers)
 
 // w3_mma4 with the LDS fragment reads one (k step, position group) ahead of the MFMAs that use them: a multiplying wave shares its
@@ -151,11 +143,7 @@ __device__ __forceinline__ float w4_inlin_s(float w0, float w1, float bc, float 
 #ifdef W4_INLIN_PACKED
   return ws_inlin(w0, w1, bc, a, s);
 #else
-  float t;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(w0), "v"(a));
-  asm("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w1), "v"(s));
-  asm("v_add_f32 %0, %0, %1" : "+v"(t) : "v"(bc));
-  return t;
+  return w3_side_s(w0, w1, bc, a, s);
 #endif
 }
 __device__ __forceinline__ float4 w4_inl_row(const W4Inl& k, int v, const float4& A, const float4& S) {

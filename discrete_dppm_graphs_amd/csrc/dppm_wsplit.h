@@ -98,6 +98,11 @@ template <int NS>
 __device__ __forceinline__ void w3_tile_store4_qc(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, unsigned q, unsigned cg) {
   const unsigned base = (4 * q) * 256 + (cg & 1) * 8;
   const unsigned kc = (cg >> 1) ^ (4 * (q & 3)) ^ (q >> 2);   // swizzled chunk of position 4q; position 4q + e: kc ^ e
+  if (NS == 1) {   // the single-piece form: without this the SLP vectoriser transposes the 4 x 4 block through a stack array (384 B / lane
+                   // of scratch traffic per tile in w4_mlp_kernel<1,..> and head3_kernel<1,..>)
+    asm("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)); asm("" : "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+    asm("" : "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w)); asm("" : "+v"(r3.x), "+v"(r3.y), "+v"(r3.z), "+v"(r3.w));
+  }
   w3_put4<NS>(T, base + ((kc ^ 0) << 4), r0.x, r1.x, r2.x, r3.x);
   w3_put4<NS>(T, base + 256 + ((kc ^ 1) << 4), r0.y, r1.y, r2.y, r3.y);
   w3_put4<NS>(T, base + 512 + ((kc ^ 2) << 4), r0.z, r1.z, r2.z, r3.z);
@@ -158,6 +163,35 @@ __device__ __forceinline__ W3Addr w3_addr(int ci, int g) {
   return a;
 }
 __device__ __forceinline__ unsigned w3_off(const W3Addr& a, int j, int s) { return a.aj[j] ^ (unsigned)(s << 6); }
+
+// w0 a + w1 s + bc with ws_inlin's three roundings, as single-lane instructions that the compiler cannot pack.  Two kernels gave wrong
+// values from run to run while hipcc had turned this expression into v_pk_mul_f32 / v_pk_fma_f32 with crossed operand halves
+// (op_sel:[0,1] op_sel_hi:[1,0]) in waves that keep vector-memory loads in flight beside other waves' MFMAs: the in_lin rows of
+// w4_mlp_kernel's stagers (operands: destination pairs of global loads) and the side-input term of head3_kernel's epilogue (operands:
+// LDS reads, the next weight fragments in flight; round 2's global-load form of it was only deterministic behind a vmcnt(0)).
+// Every build of either kernel without those packed forms is bit-exact and deterministic ("The in_lin stagers").
+// -DW3_SIDE_PACKED gives the expression back to the compiler for that experiment (tools/dbg/head_packed_ab.sh).
+__device__ __forceinline__ float w3_side_s(float w0, float w1, float bc, float a, float s) {
+#ifdef W3_SIDE_PACKED
+  return __fadd_rn(__fmaf_rn(w1, s, __fmul_rn(w0, a)), bc);
+#endif
+  float t;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(w0), "v"(a));
+  asm("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w1), "v"(s));
+  asm("v_add_f32 %0, %0, %1" : "+v"(t) : "v"(bc));
+  return t;
+}
+
+// Staging thread t -> (position quad q, channel group cg) of the role-split kernels.  The 16 lanes of a ds_write_b64 group are
+// served in one LDS cycle only if they cover 16 distinct 8-byte bank pairs of the 128-byte store row.  An image slot is (8-byte half
+// cg & 1) of (16-byte chunk (cg >> 1) ^ 4 (q & 3) ^ (q >> 2) ^ e): with the plain map (q = t & 15, cg = t >> 4) the 16 lanes share cg,
+// sit on one half and reach 8 chunks twice -- two cycles per group, a quarter of w4_mlp_kernel's LDS cycles (SQ_LDS_BANK_CONFLICT,
+// profiles/r02f_pmc_mfma_lds.txt).  Here lane bit 0 is cg's low bit and q's bit 1 (which the chunk's low three bits do not see) is
+// lane bit 4: 2 halves x 8 chunks.  A wave still covers four channel rows x 256 contiguous bytes per global load instruction.
+// (Measured: the conflict cycles go, the launch time does not move -- the stores' LDS cycles were never on the critical path.)
+__device__ __forceinline__ unsigned w4_q(int t) { return ((t >> 1) & 1) | (((t >> 4) & 1) << 1) | (((t >> 2) & 3) << 2); }
+__device__ __forceinline__ unsigned w4_cg(int t) { return (t & 1) | ((t >> 5) << 1); }
+
 
 // acc[j] += X-tile(positions 16 j ..) x W-slice over K = 128.  W_IS_A: D = W X (lane: 4 channels of one position);
 // else D = X^T W^T (lane: 4 positions of one channel).

@@ -67,7 +67,11 @@ def _replay_chain(ops, g, kind, use_probs):
         for c in range(T):
             s = sig[len(sig) - c - 1]
             a_t, _ = ops.edgeflip(x, flags, s, U=dev(U[1 + 2 * c]), want_target=False)
-            assert np.array_equal(a_t.cpu().numpy(), g["model_A"][c]), f"A_t differs at step {c}"
+            if use_probs:
+                assert np.array_equal(a_t.cpu().numpy(), g["model_A"][c]), f"A_t differs at step {c}"
+            else:
+                mism += int((a_t.cpu().numpy() != g["model_A"][c]).sum())
+                a_t = dev(g["model_A"][c])   # re-synchronise so one ulp of sigmoid cannot cascade
             lg = g["model_logits"][c]
             inp = dev(torch.sigmoid(torch.from_numpy(lg)).numpy()) if use_probs else dev(lg)
             x = ops.reverse_step_simple(a_t, inp, flags, U=dev(U[2 + 2 * c]), is_probs=use_probs)
@@ -94,13 +98,11 @@ def test_chain_golden_bit_exact_from_probs(ops, kind):
 @pytest.mark.parametrize("kind", ["simple", "vlb"])
 def test_chain_golden_from_logits(ops, kind):
     """Device sigmoid (ocml expf) vs torch-CPU sigmoid may differ in the last ulp; a Bernoulli outcome changes only if
-    u falls inside that ulp.  Allow at most 2 differing entries over the whole chain (expected: 0)."""
+    u falls inside that ulp.  Both chains are re-synchronised to the golden state after every level; at most 2 differing entries over the
+    whole chain (expected: 0)."""
     g = load(f"g4_chain_{kind}.npz")
     final, mism = _replay_chain(ops, g, kind, use_probs=False)
-    if kind == "vlb":
-        assert mism + int((final != g["final"]).sum()) <= 2
-    else:
-        assert int((final != g["final"]).sum()) <= 2 * 16
+    assert mism + int((final != g["final"]).sum()) <= 2
 
 
 # ------------------------------------------------------------------ oracle on seeded inputs, ragged sizes
