@@ -44,7 +44,9 @@ extern "C" {
  *   DPPM_PREC_BF16X3  each operand split into two bf16 pieces (hi + lo), a product = hi*hi + hi*lo + lo*hi on
  *                     v_mfma_f32_16x16x32_bf16 with float32 accumulation: ~6e-6 of the result's magnitude per Linear,
  *                     inside the 1e-3 float32 parity bar, at 3/16 of the f32 matrix time;
- *   DPPM_PREC_BF16    operands rounded to bf16, float32 accumulation (~3e-3 per Linear; tolerance stated separately). */
+ *   DPPM_PREC_BF16    operands rounded to bf16, float32 accumulation (~3e-3 per Linear).  An experiment switch for timing the
+ *                     matrix side of the split kernels: NO tolerance is claimed for it and no parity test rests on it (through
+ *                     1-3 layers of a random-init network it is 1.5e-1 of max |logit| off). */
 #define DPPM_PREC_F32 0
 #define DPPM_PREC_BF16X3 1
 #define DPPM_PREC_BF16 2
