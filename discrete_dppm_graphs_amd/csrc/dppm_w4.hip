@@ -34,6 +34,11 @@ __device__ unsigned long long g_w4_trace[3 * 3 * 256];
 #endif
 
 // (stager thread map w4_q / w4_cg: dppm_wsplit.h)
+#ifndef W4_PKEPI
+#define W4_PKEPI 0
+#endif
+__device__ __forceinline__ floatx2 w4_pk_add(floatx2 a, floatx2 b) { floatx2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ floatx2 w4_pk_mul(floatx2 a, floatx2 b) { floatx2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 struct W4Pre { float4 a, b, c, d, sc, sh; float m; };   // one tile in flight per staging thread (named members: registers)
 
 // w3_mma4 with the LDS fragment reads one (k step, position group) ahead of the MFMAs that use them: a multiplying wave shares its
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
         xa = w4_inl_row(inl, 0, A4, S4); xb = w4_inl_row(inl, 1, A4, S4); xc = w4_inl_row(inl, 2, A4, S4); xd = w4_inl_row(inl, 3, A4, S4);
         if (!in) xa = xb = xc = xd = z;
       } else if (NRM && ls == 1) {                           // the skip input's instance norm (uniform branch)
-        w3_affine(xa, pre.sc.x, pre.sh.x); w3_affine(xb, pre.sc.y, pre.sh.y); w3_affine(xc, pre.sc.z, pre.sh.z); w3_affine(xd, pre.sc.w, pre.sh.w);
+        w3_affine<true>(xa, pre.sc.x, pre.sh.x); w3_affine<true>(xb, pre.sc.y, pre.sh.y); w3_affine<true>(xc, pre.sc.z, pre.sh.z); w3_affine<true>(xd, pre.sc.w, pre.sh.w);
       }
       w3_tile_store4_qc<NS>(xa, xb, xc, xd, Xs + buf * BUF, sq, scg);
       if (NRM && ls == 0 && tid < 64) Ms[(li & 1) * 64 + tid] = (li < nloc && p0 + lane < P) ? pre.m : 0.f;
@@ -283,7 +288,10 @@ __global__ __launch_bounds__(W4_THREADS) void w4_lin2_kernel(const WsArgs a) {
       if (g == 0) *reinterpret_cast<float2*>(a.stat + ((size_t)t * WS_H + ch) * 2) = make_float2(piv + dm, fmaxf(s2 - s1 * dm, 0.f));
       if (w8 == 0 && lane == 0) a.cnt[t] = n;
     }
-    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, nullptr, m0, P - p0, bv, false, false);   // (wide stores, ws_store_wide / _lds: 0.41 - 0.42 ms against 0.40 ms)
+    // NRM: the RAW result is what the layer tensor holds from here on (its norm is applied by the consumers), with masked positions
+    // zeroed as the reference's norm does (model/ppgn.py:315): they restart from `shift` in every consumer and cannot grow from layer
+    // to layer (ws_mask_mul: 0 * anything = 0).  Unmasked results do not depend on them (a position is a column of every product).
+    ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, NRM ? Ms + (i & 1) * 64 : nullptr, m0, P - p0, bv, false, false);   // (wide stores, ws_store_wide / _lds: 0.41 - 0.42 ms against 0.40 ms)
     __syncthreads();
   }
 }
@@ -441,6 +449,9 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   if (!second) {
     // first product, D = W1 X: the lane holds channels 32 pw + 16 cb + 4 g + r of position 16 j + ci -> hidden image
     const unsigned hbase = ci * 256 + (g & 1) * 8;
+#if W4_PKEPI
+    const floatx2 slope2 = {kSlope, kSlope};
+#endif
     float4 b1w[2];                                           // loaded once: inside the loop every tile would wait for a global load
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -461,8 +472,18 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
           const float4 b1 = b1w[cb];
           const unsigned hchunk = (unsigned)(2 * (2 * pw + cb) + (g >> 1)) ^ (unsigned)ci;
           unsigned h01, l01 = 0, h23, l23 = 0;
+#if W4_PKEPI
+          // (experiment, off: bias and the LeakyReLU's slope product as packed instructions on the accumulator's aligned register pairs;
+          // 32 vector instructions fewer per tile and wave, bit-identical, and no faster: 0.5025 against 0.4937 ms together with W3_NATPAIR)
+          const floatx2 v01 = w4_pk_add(floatx2{acc[cb][j][0], acc[cb][j][1]}, floatx2{b1.x, b1.y});
+          const floatx2 v23 = w4_pk_add(floatx2{acc[cb][j][2], acc[cb][j][3]}, floatx2{b1.z, b1.w});
+          const floatx2 s01 = w4_pk_mul(v01, slope2), s23 = w4_pk_mul(v23, slope2);
+          w3_split2<NS>(fmaxf(v01[0], s01[0]), fmaxf(v01[1], s01[1]), h01, l01);
+          w3_split2<NS>(fmaxf(v23[0], s23[0]), fmaxf(v23[1], s23[1]), h23, l23);
+#else
           w3_split2<NS>(ws_leaky(acc[cb][j][0] + b1.x), ws_leaky(acc[cb][j][1] + b1.y), h01, l01);
           w3_split2<NS>(ws_leaky(acc[cb][j][2] + b1.z), ws_leaky(acc[cb][j][3] + b1.w), h23, l23);
+#endif
           const unsigned off = hbase + j * 4096 + ((hchunk ^ j) << 4);
           *reinterpret_cast<uint2*>(Hb + off) = make_uint2(h01, h23);
           if (NS > 1) *reinterpret_cast<uint2*>(Hb + W3_IMG + off) = make_uint2(l01, l23);

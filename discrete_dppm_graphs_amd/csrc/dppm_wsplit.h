@@ -94,6 +94,23 @@ __device__ __forceinline__ void w3_put4(char* __restrict__ T, unsigned off, floa
   if (NS > 1) *reinterpret_cast<uint2*>(T + W3_IMG + off) = make_uint2(l01, l23);
 }
 // thread (q, cg): channels 4 cg .. 4 cg + 3 of positions 4 q .. 4 q + 3
+// -DW3_NATPAIR=1 (an experiment, off): the remainders x - hi formed in the registers' pairing (two POSITIONS of one channel: the halves
+// of a loaded float4 are aligned register pairs) with one v_pk_add_f32 per two values, which saves the v_mov per pair that hipcc pays
+// for packing the scalar form across float4s (33 of a staging wave's ~190 vector instructions per tile).  Bit-identical by
+// construction and measured SLOWER in the MLP pair (0.5025 against 0.4937 ms with the packed first-product epilogue, W4_PKEPI); and
+// with the values in that pairing hipcc turns the norm's x * scale + shift in head3_kernel's stagers into v_pk_fma_f32 with
+// broadcast operand halves (op_sel:[0,1,1], op_sel_hi:[1,0,0]) -- that build is grossly nondeterministic (thousands of logits per
+// forward), the third sighting of the packed operand-select effect and its most reproducible one.
+#ifndef W3_NATPAIR
+#define W3_NATPAIR 0
+#endif
+__device__ __forceinline__ floatx2 w3_sub2(floatx2 x, unsigned h0, unsigned h1, bool high) {
+  floatx2 h = high ? floatx2{__uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 & 0xffff0000u)}
+                   : floatx2{__uint_as_float(h0 << 16), __uint_as_float(h1 << 16)};
+  floatx2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(h));
+  return d;
+}
 template <int NS>
 __device__ __forceinline__ void w3_tile_store4_qc(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, unsigned q, unsigned cg) {
   const unsigned base = (4 * q) * 256 + (cg & 1) * 8;
@@ -102,11 +119,36 @@ __device__ __forceinline__ void w3_tile_store4_qc(float4 r0, float4 r1, float4 r
                    // of scratch traffic per tile in w4_mlp_kernel<1,..> and head3_kernel<1,..>)
     asm("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)); asm("" : "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
     asm("" : "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w)); asm("" : "+v"(r3.x), "+v"(r3.y), "+v"(r3.z), "+v"(r3.w));
+    w3_put4<NS>(T, base + ((kc ^ 0) << 4), r0.x, r1.x, r2.x, r3.x);
+    w3_put4<NS>(T, base + 256 + ((kc ^ 1) << 4), r0.y, r1.y, r2.y, r3.y);
+    w3_put4<NS>(T, base + 512 + ((kc ^ 2) << 4), r0.z, r1.z, r2.z, r3.z);
+    w3_put4<NS>(T, base + 768 + ((kc ^ 3) << 4), r0.w, r1.w, r2.w, r3.w);
+    return;
   }
+#if W3_NATPAIR
+  // hi pieces, position e: (channels 0, 1) and (channels 2, 3)
+  const unsigned ha0 = w3_pack(r0.x, r1.x), hb0 = w3_pack(r2.x, r3.x), ha1 = w3_pack(r0.y, r1.y), hb1 = w3_pack(r2.y, r3.y);
+  const unsigned ha2 = w3_pack(r0.z, r1.z), hb2 = w3_pack(r2.z, r3.z), ha3 = w3_pack(r0.w, r1.w), hb3 = w3_pack(r2.w, r3.w);
+  // remainders, channel v: positions (0, 1) and (2, 3)
+  const floatx2 d0a = w3_sub2(floatx2{r0.x, r0.y}, ha0, ha1, false), d0b = w3_sub2(floatx2{r0.z, r0.w}, ha2, ha3, false);
+  const floatx2 d1a = w3_sub2(floatx2{r1.x, r1.y}, ha0, ha1, true), d1b = w3_sub2(floatx2{r1.z, r1.w}, ha2, ha3, true);
+  const floatx2 d2a = w3_sub2(floatx2{r2.x, r2.y}, hb0, hb1, false), d2b = w3_sub2(floatx2{r2.z, r2.w}, hb2, hb3, false);
+  const floatx2 d3a = w3_sub2(floatx2{r3.x, r3.y}, hb0, hb1, true), d3b = w3_sub2(floatx2{r3.z, r3.w}, hb2, hb3, true);
+  const unsigned o0 = base + ((kc ^ 0) << 4), o1 = base + 256 + ((kc ^ 1) << 4), o2 = base + 512 + ((kc ^ 2) << 4), o3 = base + 768 + ((kc ^ 3) << 4);
+  *reinterpret_cast<uint2*>(T + o0) = make_uint2(ha0, hb0);
+  *reinterpret_cast<uint2*>(T + o1) = make_uint2(ha1, hb1);
+  *reinterpret_cast<uint2*>(T + o2) = make_uint2(ha2, hb2);
+  *reinterpret_cast<uint2*>(T + o3) = make_uint2(ha3, hb3);
+  *reinterpret_cast<uint2*>(T + W3_IMG + o0) = make_uint2(w3_pack(d0a[0], d1a[0]), w3_pack(d2a[0], d3a[0]));
+  *reinterpret_cast<uint2*>(T + W3_IMG + o1) = make_uint2(w3_pack(d0a[1], d1a[1]), w3_pack(d2a[1], d3a[1]));
+  *reinterpret_cast<uint2*>(T + W3_IMG + o2) = make_uint2(w3_pack(d0b[0], d1b[0]), w3_pack(d2b[0], d3b[0]));
+  *reinterpret_cast<uint2*>(T + W3_IMG + o3) = make_uint2(w3_pack(d0b[1], d1b[1]), w3_pack(d2b[1], d3b[1]));
+#else
   w3_put4<NS>(T, base + ((kc ^ 0) << 4), r0.x, r1.x, r2.x, r3.x);
   w3_put4<NS>(T, base + 256 + ((kc ^ 1) << 4), r0.y, r1.y, r2.y, r3.y);
   w3_put4<NS>(T, base + 512 + ((kc ^ 2) << 4), r0.z, r1.z, r2.z, r3.z);
   w3_put4<NS>(T, base + 768 + ((kc ^ 3) << 4), r0.w, r1.w, r2.w, r3.w);
+#endif
 }
 template <int NS>
 __device__ __forceinline__ void w3_tile_store4(float4 r0, float4 r1, float4 r2, float4 r3, char* __restrict__ T, int tid) {
@@ -151,7 +193,17 @@ __device__ __forceinline__ void w3_load_tab(float* __restrict__ Tb, const float*
     Tb[tid] = aff[(size_t)b * 256 + (tid & 255)];
   }
 }
-__device__ __forceinline__ void w3_affine(float4& v, float sc, float sh) { v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh; }
+// x * scale + shift on four positions of one channel.  The empty asm hides from the compiler that neighbouring channels' (scale, shift)
+// sit in neighbouring registers of one LDS read: knowing it, hipcc broadcasts the HIGH register of such a pair into both halves of a
+// v_pk_fma_f32 (op_sel:[0,1,1]) -- the operand-select form that computes with the wrong register from time to time on this part
+// (DESIGN.md section 4); a scalar of unknown origin is broadcast from the LOW half (op_sel_hi:[1,0,0]), which never failed.
+// OPAQUE is set where hipcc was seen to do that (w4_lin2_kernel<3, true, false>'s stagers; everywhere, it costs w4_mlp_kernel 16 spilled
+// registers); tests/test_isa_gate.py fails the build on any such instruction in the default inference kernels, whoever produced it.
+template <bool OPAQUE = false>
+__device__ __forceinline__ void w3_affine(float4& v, float sc, float sh) {
+  if (OPAQUE) asm("" : "+v"(sc), "+v"(sh));
+  v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+}
 
 // per-lane byte offsets of the fragment (position 16 j + ci, k = 32 s + 8 g ..): aj[j] ^ (s << 6)
 // (chunk (4s | g) ^ ci ^ j: bits 2-3 are s ^ (ci >> 2), folded into aj as (ci >> 2) << 6, so s enters as one XOR)
@@ -466,7 +518,7 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_mlp_kernel(const WsArgs a) {
             v.x += bv[0]; v.y += bv[0]; v.z += bv[0]; v.w += bv[0];
             if (maskp) {
               const float4 m = *reinterpret_cast<const float4*>(Mb + pj);
-              v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+              ws_mask_mul4(v, m);
             }
             *reinterpret_cast<float4*>(Yt + r0 + 16 * (jb + j)) = v;
           }
@@ -667,7 +719,9 @@ __global__ __launch_bounds__(W3M_THREADS) void w3_lin2_kernel(const WsArgs a) {
         if (g == 0) *reinterpret_cast<float2*>(a.stat + ((size_t)t * WS_H + ch) * 2) = make_float2(mean, q);
         if (tid == 0) a.cnt[t] = n;
       }
-      ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, a.maskp ? a.maskp + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
+      // NRM: the raw result with masked positions zeroed (see w4_lin2_kernel's store)
+      const float* Mo = NRM ? a.maskstat : a.maskp;
+      ws_store_out(acc, J.Y + (size_t)b * J.y_bs + p0, r0, Mo ? Mo + (size_t)b * P + p0 : nullptr, m0, P - p0, bv, a.act != 0,
                    J.accumulate != 0);
     }
     __syncthreads();

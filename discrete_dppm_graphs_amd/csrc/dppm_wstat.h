@@ -139,6 +139,17 @@ __device__ __forceinline__ WsWho ws_who(int njobs) {
 
 __device__ __forceinline__ float ws_leaky(float v) { return fmaxf(v, kSlope * v); }   // = v > 0 ? v : slope v for 0 < slope < 1, one instruction less
 __device__ __forceinline__ float4 ws_f4(const floatx4& a) { return make_float4(a[0], a[1], a[2], a[3]); }
+// value * mask with 0 * anything = 0 (v_mul_legacy_f32): since the instance norm is folded into its consumers the layer tensors hold RAW
+// m4 results, and a masked position is never zeroed between layers -- it evolves as rstd (W x + b) - mean rstd with rstd up to 1/sqrt(eps)
+// on a near-constant channel, so after enough layers it may be Inf or NaN, and Inf * 0 = NaN in o1 / o2 would reach every logit of the
+// graph through the contraction.  The reference zeroes these positions at every norm (model/ppgn.py:315).  For mask values in {0, 1}
+// and finite values this is the plain product (up to the sign of a zero).
+__device__ __forceinline__ float ws_mask_mul(float v, float m) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+  return r;
+}
+__device__ __forceinline__ void ws_mask_mul4(float4& v, const float4& m) { v.x = ws_mask_mul(v.x, m.x); v.y = ws_mask_mul(v.y, m.y); v.z = ws_mask_mul(v.z, m.z); v.w = ws_mask_mul(v.w, m.w); }
 
 // result tile -> global: optional LeakyReLU, mask, accumulate.  Yt / Mt: uniform pointers to the tile's first position;
 // r0 = ch * P + 4 g, m0 = 4 g: the lane's offsets; lim = positions left in the plane from the tile's start.
@@ -152,7 +163,7 @@ __device__ __forceinline__ void ws_store_out(const floatx4 (&acc)[4], float* __r
       if (act) { v.x = ws_leaky(v.x); v.y = ws_leaky(v.y); v.z = ws_leaky(v.z); v.w = ws_leaky(v.w); }
       if (Mt) {
         const float4 m = *reinterpret_cast<const float4*>(Mt + m0 + 16 * j);
-        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        ws_mask_mul4(v, m);
       }
       if (accumulate) {
         const float4 o = *reinterpret_cast<const float4*>(Yt + r0 + 16 * j);
@@ -212,7 +223,7 @@ __device__ __forceinline__ void ws_store_wide(floatx4 (&acc)[4], float* __restri
       v.x += bk; v.y += bk; v.z += bk; v.w += bk;
     }
     if (act) { v.x = ws_leaky(v.x); v.y = ws_leaky(v.y); v.z = ws_leaky(v.z); v.w = ws_leaky(v.w); }
-    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    ws_mask_mul4(v, m);
     if (accumulate) {
       const float4 o = *reinterpret_cast<const float4*>(Y + (size_t)k * P);
       v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -239,7 +250,7 @@ __device__ __forceinline__ void ws_store_wide_lds(const floatx4 (&acc)[4], float
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float4 v = *reinterpret_cast<const float4*>(R + (4 * k + g) * WS_WIDE_PITCH + pos);
-    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;   // (plain product: the sources' masked positions are finite, see w4_lin2_kernel's store; ws_mask_mul here costs 4 %)
     if (pos < lim) *reinterpret_cast<float4*>(Y + (size_t)(4 * k) * P) = v;
   }
 }

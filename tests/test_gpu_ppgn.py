@@ -465,6 +465,39 @@ def test_mlp_pair_block_reduced_precision(ops, precision, tol, P, B, form):
         close(o.cpu().numpy(), out, tol=tol)
 
 
+@pytest.mark.parametrize("form", ["role_split", "fallback"])
+def test_layer_tensors_hold_zeros_at_masked_positions(ops, form):
+    """With the instance norm folded into its consumers the layer tensors hold RAW m4 results.  The reference zeroes masked
+    positions at every norm (model/ppgn.py:315); left alone they would evolve as rstd (W x + b) - mean rstd, with rstd up to
+    1/sqrt(eps) per layer on a near-constant channel, towards Inf -- and Inf * 0 = NaN in the next MLP's masked output would reach
+    every logit of the graph through the contraction.  m4 therefore stores exact zeros there (0 * anything = 0): checked on the
+    workspace's CAT planes of every layer after an inference forward with ragged graphs."""
+    from oracle import ppgn as op
+    B, N, L, H = 3, 50, 4, 128
+    rng = np.random.default_rng(4100)
+    A, mask = rand_case(rng, B, N)
+    assert (mask == 0).any()
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=41)
+    tensors = {k: dev(v.detach().numpy()) for k, v in W.items()}
+    pack = ops.ParamPack(tensors, L, H)
+    ld = -(-N // 4) * 4; P = N * ld; CT = 2 + L * H
+    al = lambda n: -(-n // 64) * 64
+    with ops.debug_switch(DISABLE_W4=int(form == "fallback")):
+        ws = ops.ppgn_workspace(B, N, H, L, False, "cuda"); ws.fill_(float("nan"))
+        logits = ops.ppgn_forward(pack, dev(A), dev(mask), dev(np.asarray(sigma, np.float32)), ws, training=False, precision="bf16x3")
+        torch.cuda.synchronize()
+    assert torch.isfinite(logits).all()
+    off = al(B * P) + al(B)
+    cat = ws[off:off + B * CT * P].cpu().numpy().reshape(B, CT, N, ld)
+    m2 = np.zeros((B, N, ld), np.float32); m2[:, :, :N] = np.asarray(mask, np.float32).reshape(B, N, N)
+    u = cat[:, 2:].reshape(B, L, H, N, ld)
+    dead = np.broadcast_to((m2 == 0)[:, None, None], u.shape)
+    assert np.isfinite(u).all()
+    assert (u[dead] == 0).all(), f"{int((u[dead] != 0).sum())} nonzero values at masked positions of the layer tensors"
+    assert (u[~dead] != 0).mean() > 0.99
+
+
 @pytest.mark.parametrize("precision,ltol", [("bf16x3", 1e-3), ("bf16", 1.5e-1)])
 @pytest.mark.parametrize("B,N,L", [(2, 40, 3), (1, 200, 2), (2, 64, 8)])
 def test_forward_reduced_precision(ops, precision, ltol, B, N, L):

@@ -81,3 +81,18 @@ def test_inlin_stagers_have_no_packed_operand_selects(kernels):
         assert "v_mfma" in body
         hits = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*op_sel", body)
         assert not hits, f"{sym}: {len(hits)} packed-f32 instructions with operand-half selects, e.g. {hits[0]}"
+
+
+def test_default_inference_kernels_take_no_high_register_into_the_low_half(kernels):
+    """The sharper form of the rule: a packed-f32 instruction whose op_sel has a bit set -- the LOW result half reads
+    the HIGH register of a source pair -- is the form that misbehaved in all three sightings (broadcast-high in the in_lin stagers and
+    in the read-out's norm, crossed in the read-out's epilogue); broadcasts from the low register (op_sel_hi only) never did.  None may
+    appear in any split-precision kernel of the default inference path."""
+    cos, _ = kernels
+    dis = "".join(subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", str(co)], text=True) for co in cos)
+    seen = 0
+    for m in re.finditer(r"<(_ZN4dppm\d+(?:w4_mlp_kernelILi3|w4_lin2_kernelILi3|head3_kernelILi3|plane4_kernelILi\d+ELi3)\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
+        seen += 1
+        hits = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*op_sel:\[[0-9,]*1[^\n]*", m.group(2))
+        assert not hits, f"{m.group(1)}: {len(hits)} packed-f32 instructions select a high register for the low half, e.g. {hits[0]}"
+    assert seen >= 10, seen
