@@ -83,16 +83,20 @@ def test_inlin_stagers_have_no_packed_operand_selects(kernels):
         assert not hits, f"{sym}: {len(hits)} packed-f32 instructions with operand-half selects, e.g. {hits[0]}"
 
 
-def test_default_inference_kernels_take_no_high_register_into_the_low_half(kernels):
+def test_no_packed_f32_operand_selects_anywhere(kernels):
     """The sharper form of the rule: a packed-f32 instruction whose op_sel has a bit set -- the LOW result half reads
     the HIGH register of a source pair -- is the form that misbehaved in all three sightings (broadcast-high in the in_lin stagers and
-    in the read-out's norm, crossed in the read-out's epilogue); broadcasts from the low register (op_sel_hi only) never did.  None may
-    appear in any split-precision kernel of the default inference path."""
+    in the read-out's norm, crossed in the read-out's epilogue); broadcasts from the low register (op_sel_hi only) never did.  The
+    library is built with -fno-slp-vectorize, which leaves no packed-f32 instruction with either modifier in ANY kernel; a set op_sel
+    bit anywhere fails the build check, and so does an op_sel_hi form in the split-precision kernels of the default inference path."""
     cos, _ = kernels
     dis = "".join(subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", str(co)], text=True) for co in cos)
     seen = 0
-    for m in re.finditer(r"<(_ZN4dppm\d+(?:w4_mlp_kernelILi3|w4_lin2_kernelILi3|head3_kernelILi3|plane4_kernelILi\d+ELi3)\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
+    for m in re.finditer(r"<(_Z\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
         seen += 1
         hits = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*op_sel:\[[0-9,]*1[^\n]*", m.group(2))
         assert not hits, f"{m.group(1)}: {len(hits)} packed-f32 instructions select a high register for the low half, e.g. {hits[0]}"
-    assert seen >= 10, seen
+        if re.search(r"w4_mlp_kernelILi3|w4_lin2_kernelILi3|head3_kernelILi3|plane4_kernelILi\d+ELi3", m.group(1)):
+            hits = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*op_sel[^\n]*", m.group(2))
+            assert not hits, f"{m.group(1)}: {len(hits)} packed-f32 instructions with operand-half selects, e.g. {hits[0]}"
+    assert seen > 100, seen
