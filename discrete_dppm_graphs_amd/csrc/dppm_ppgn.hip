@@ -35,7 +35,7 @@ struct Layout {
   size_t hid1, hid2, o1, o2, mm;   // per-layer saves (training): base + l * S
   size_t rstd;                     // [L][B][H]
   size_t himg;                     // inference, H = 128: bf16 weight fragments of the fused read-out head (dppm_head.h)
-  size_t nstat, ncnt, naff;        // inference, H = 128: per-tile statistics [B*tpp][128][2], counts [B*tpp], (scale, shift) tables [L+1][B][2][128]
+  size_t nstat, ncnt, naff;        // inference, H = 128 / 32: per-tile statistics [B*tpp][H][2], counts [B*tpp], (scale, shift) tables [L+1][B][2][H]
   size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to four 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
@@ -74,11 +74,11 @@ Layout make_layout(int B, int N, int H, int L, int training) {
   if (!training) {
     for (int i = 0; i < 4; ++i) w.tmp[i] = bump(off, w.S);
     w.himg = H == WS_H ? bump(off, head3_wimg_floats(L)) : 0;
-    if (H == WS_H) {
+    if (H == WS_H || H == 32) {   // instance norm folded into its producer and consumers (H = 32: the wide kernels)
       const size_t ntiles = (size_t)B * ((w.P + WS_TP - 1) / WS_TP);
-      w.nstat = bump(off, ntiles * WS_H * 2);
+      w.nstat = bump(off, ntiles * H * 2);
       w.ncnt = bump(off, ntiles);
-      w.naff = bump(off, (size_t)(L + 1) * B * 2 * WS_H);
+      w.naff = bump(off, (size_t)(L + 1) * B * 2 * H);
     }
   } else {
     w.tmp[3] = bump(off, w.S);   // y
@@ -274,17 +274,17 @@ inline void launch_inorm_bwd(int P, int nplanes, hipStream_t st, Args... args) {
 // One workgroup per (graph, 16 channels): 64 tile groups x 16 channels (a tile's 16 float2 are 128 contiguous bytes).
 constexpr int NF_CH = 16, NF_GRP = 64;
 __global__ __launch_bounds__(NF_CH * NF_GRP) void norm_finalize_kernel(const float* __restrict__ stat, const float* __restrict__ cnt, int tpp,
-                                                                       float* __restrict__ aff) {
+                                                                       float* __restrict__ aff, int C) {   // C channels (a multiple of NF_CH); grid B * C / NF_CH
   __shared__ double s0[NF_GRP][NF_CH], s1[NF_GRP][NF_CH];
   __shared__ double tot_n[NF_CH], tot_m[NF_CH];
-  const int b = blockIdx.x / (WS_H / NF_CH), c0 = (blockIdx.x % (WS_H / NF_CH)) * NF_CH;
+  const int b = blockIdx.x / (C / NF_CH), c0 = (blockIdx.x % (C / NF_CH)) * NF_CH;
   const int c = threadIdx.x % NF_CH, grp = threadIdx.x / NF_CH;
   const size_t base = (size_t)b * tpp;
   // pass 1: n and n * mean
   double n = 0.0, sm = 0.0;
   for (int t = grp; t < tpp; t += NF_GRP) {
     const double nt = cnt[base + t];
-    const float2 s = *reinterpret_cast<const float2*>(stat + ((base + t) * WS_H + c0 + c) * 2);
+    const float2 s = *reinterpret_cast<const float2*>(stat + ((base + t) * C + c0 + c) * 2);
     n += nt;
     sm += nt > 0.0 ? nt * (double)s.x : 0.0;
   }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NF_CH * NF_GRP) void norm_finalize_kernel(const flo
   double m2 = 0.0;
   for (int t = grp; t < tpp; t += NF_GRP) {
     const double nt = cnt[base + t];
-    const float2 s = *reinterpret_cast<const float2*>(stat + ((base + t) * WS_H + c0 + c) * 2);
+    const float2 s = *reinterpret_cast<const float2*>(stat + ((base + t) * C + c0 + c) * 2);
     const double d = (double)s.x - mean;
     m2 += nt > 0.0 ? (double)s.y + nt * d * d : 0.0;
   }
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(NF_CH * NF_GRP) void norm_finalize_kernel(const flo
     const double nn = tot_n[c];
     const float var = nn > 0.0 ? (float)(a0 / nn) : 0.f;
     const float rstd = 1.f / sqrtf(var + 1e-5f);
-    aff[(size_t)b * 2 * WS_H + c0 + c] = rstd;
-    aff[(size_t)b * 2 * WS_H + WS_H + c0 + c] = (float)(-mean) * rstd;
+    aff[(size_t)b * 2 * C + c0 + c] = rstd;
+    aff[(size_t)b * 2 * C + C + c0 + c] = (float)(-mean) * rstd;
   }
 }
 // debug (DPPM_DBG & 4): the table from the standalone pass's own statistics
@@ -834,6 +834,46 @@ __device__ __forceinline__ void a32_leaky(A32& a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float v = a.a[j][co][r]; a.a[j][co][r] = v > 0.f ? v : kSlope * v; }
 }
+// the source's folded instance norm: x * scale + shift per channel; a lane's eight (scale, shift) pairs of the graph's [2][32] table
+// (norm_finalize_kernel)
+struct T32 { float sc[2][4], sh[2][4]; };
+__device__ __forceinline__ T32 t32_load(const float* __restrict__ T, int q) {
+  T32 t;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t.sc[ci][r] = T[16 * ci + 4 * q + r]; t.sh[ci][r] = T[32 + 16 * ci + 4 * q + r]; }
+  return t;
+}
+__device__ __forceinline__ void x32_affine(X32& x, const T32& t) {
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sc = t.sc[ci][r], sh = t.sh[ci][r];
+      float4& v = x.v[ci][r];
+      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+    }
+}
+__device__ __forceinline__ void x32_mask(X32& x, const float4& mk) {   // exact zeros at masked positions (model/ppgn.py:315)
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4& v = x.v[ci][r];
+      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+}
+// sum over the 16 lanes n of a lane's row (same q), in every lane: four DPP adds (quad swaps, then the mirrored half row and the mirrored
+// row bring in the other quad's and the other half's sums); __shfl_xor would be four ds_bpermute round trips through the LDS crossbar
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
+  return v;
+}
 // wave -> (graph, first position) of its 64-position group g; P % 4 == 0, a group never crosses a graph
 struct G32 { int b, p0; bool ok; };
 __device__ __forceinline__ G32 g32_of(int g, int gpp, int P, int n) {
@@ -850,7 +890,8 @@ __global__ __launch_bounds__(256) void mlp32w_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ b0a, const float* __restrict__ b0b,
                                                          const float* __restrict__ b1a, const float* __restrict__ b1b,
                                                          const float* __restrict__ maskp, float* __restrict__ o1, float* __restrict__ o2,
-                                                         float* __restrict__ hid1, float* __restrict__ hid2, long hs, int P, int B) {
+                                                         float* __restrict__ hid1, float* __restrict__ hid2, long hs, int P, int B,
+                                                         const float* __restrict__ aff) {   // aff: null, or [B][2][32] (scale, shift) of the source's instance norm
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int gpp = (P + 63) >> 6, ngroups = B * gpp;
   const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
@@ -860,11 +901,13 @@ __global__ __launch_bounds__(256) void mlp32w_fwd_kernel(const float* __restrict
   X32 xn = x32_load(X + (size_t)nx.b * x_bs + nx.p0, P, q, n, nx.ok);
   for (int g = wave0; g < ngroups; g += nwaves) {
     const G32 at = nx;
-    const X32 x = xn;
+    X32 x = xn;
     if (g + nwaves < ngroups) {                              // the next group's source is in flight during this group's products
       nx = g32_of(g + nwaves, gpp, P, n);
       xn = x32_load(X + (size_t)nx.b * x_bs + nx.p0, P, q, n, nx.ok);
     }
+    // (the table is read where it is used -- L2 hits; carried with the prefetch, 16 more registers, the kernel pair was 9 % slower)
+    if (aff) x32_affine(x, t32_load(aff + (size_t)at.b * 64, q));
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     if (maskp && at.ok) mk = *reinterpret_cast<const float4*>(maskp + (size_t)at.b * P + at.p0 + 4 * n);
 #pragma unroll
@@ -891,7 +934,11 @@ __global__ __launch_bounds__(256) void mlp32w_fwd_kernel(const float* __restrict
 // m4 of a hidden-32 layer on cat(mm, x) (model/ppgn.py:66-69): Y = W[:, 0:32] mm + W[:, 32:64] x + b, both halves resident (32 registers)
 __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
                                                        const float* __restrict__ X1, long x1_bs, const float* __restrict__ X2, long x2_bs,
-                                                       float* __restrict__ Y, long y_bs, int P, int B) {
+                                                       float* __restrict__ Y, long y_bs, int P, int B,
+                                                       const float* __restrict__ aff2, const float* __restrict__ maskp, float* __restrict__ stat, float* __restrict__ cnt) {
+  // stat != null (instance norm folded, as for H = 128): X2 goes through its own norm (aff2: [B][2][32], null for layer 0), Y is the RAW
+  // result with exact zeros at masked positions, and per 64-position group g and channel the masked (mean, centred sum of squares) go to
+  // stat[g][32][2], the group's unmasked count to cnt[g] (two passes over the wave's registers; merged by norm_finalize_kernel)
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int gpp = (P + 63) >> 6, ngroups = B * gpp;
   const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
@@ -901,17 +948,37 @@ __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__
   X32 x1n = x32_load(X1 + (size_t)nx.b * x1_bs + nx.p0, P, q, n, nx.ok), x2n = x32_load(X2 + (size_t)nx.b * x2_bs + nx.p0, P, q, n, nx.ok);
   for (int g = wave0; g < ngroups; g += nwaves) {
     const G32 at = nx;
-    const X32 x1 = x1n, x2 = x2n;
+    const X32 x1 = x1n;
+    X32 x2 = x2n;
     if (g + nwaves < ngroups) {
       nx = g32_of(g + nwaves, gpp, P, n);
       x1n = x32_load(X1 + (size_t)nx.b * x1_bs + nx.p0, P, q, n, nx.ok);
       x2n = x32_load(X2 + (size_t)nx.b * x2_bs + nx.p0, P, q, n, nx.ok);
     }
+    if (aff2) x32_affine(x2, t32_load(aff2 + (size_t)at.b * 64, q));
     A32 acc;
     a32_zero(acc);
     a32_mma(acc, wa, x1);
     a32_mma(acc, wb, x2);
     a32_bias(acc, bias, q);
+    if (stat) {
+      const float4 mk = at.ok ? *reinterpret_cast<const float4*>(maskp + (size_t)at.b * P + at.p0 + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool m0 = mk.x > 0.f, m1 = mk.y > 0.f, m2 = mk.z > 0.f, m3 = mk.w > 0.f;
+      const float nt = row16_sum((m0 ? 1.f : 0.f) + (m1 ? 1.f : 0.f) + (m2 ? 1.f : 0.f) + (m3 ? 1.f : 0.f));
+      const float rn = 1.f / fmaxf(nt, 1.f);
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = acc.a[0][co][r], v1 = acc.a[1][co][r], v2 = acc.a[2][co][r], v3 = acc.a[3][co][r];
+          const float mean = row16_sum(((m0 ? v0 : 0.f) + (m1 ? v1 : 0.f)) + ((m2 ? v2 : 0.f) + (m3 ? v3 : 0.f))) * rn;
+          const float d0 = m0 ? v0 - mean : 0.f, d1 = m1 ? v1 - mean : 0.f, d2 = m2 ? v2 - mean : 0.f, d3 = m3 ? v3 - mean : 0.f;
+          const float ss = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          if (n == 0) *reinterpret_cast<float2*>(stat + ((size_t)g * 32 + 16 * co + 4 * q + r) * 2) = make_float2(mean, ss);
+          acc.a[0][co][r] = m0 ? v0 : 0.f; acc.a[1][co][r] = m1 ? v1 : 0.f; acc.a[2][co][r] = m2 ? v2 : 0.f; acc.a[3][co][r] = m3 ? v3 : 0.f;
+        }
+      if (lane == 0) cnt[g] = nt;
+    }
     a32_store(acc, Y + (size_t)at.b * y_bs + at.p0, P, q, n, at.ok);
   }
 }
@@ -923,7 +990,8 @@ __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__
 constexpr int H32_MAXL = 16;
 __global__ __launch_bounds__(256) void head32w_kernel(const float* __restrict__ cat, long cat_bs, const float* __restrict__ Wc, int ldc, const float* __restrict__ bc,
                                                       const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wf, const float* __restrict__ bf,
-                                                      float* __restrict__ Rs, float* __restrict__ As, long hs, float* __restrict__ logits, int N, int ld, int L, int B) {
+                                                      float* __restrict__ Rs, float* __restrict__ As, long hs, float* __restrict__ logits, int N, int ld, int L, int B,
+                                                      const float* __restrict__ aff, const float* __restrict__ maskp) {   // aff: null, or [L][B][2][32]: the sources are RAW (with maskp)
   extern __shared__ float wlds[];                            // [(2 + 32 L)][33]
   const int P = N * ld, K = 2 + 32 * L;
   for (int i = threadIdx.x; i < 32 * K; i += blockDim.x) { const int o = i / K, k = i - o * K; wlds[k * 33 + o] = Wc[(size_t)o * ldc + k]; }
@@ -956,8 +1024,11 @@ __global__ __launch_bounds__(256) void head32w_kernel(const float* __restrict__ 
           for (int j = 0; j < 4; ++j) R.a[j][co][r] = c0 * f4_at(a4, j) + c1 * f4_at(s4, j);
         }
     }
+    float4 mk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aff && at.ok) mk = *reinterpret_cast<const float4*>(maskp + (size_t)at.b * P + at.p0 + 4 * n);
     for (int l = 0; l < L; ++l) {
-      const X32 x = x32_load(cp + (size_t)(2 + 32 * l) * P, P, q, n, at.ok);
+      X32 x = x32_load(cp + (size_t)(2 + 32 * l) * P, P, q, n, at.ok);
+      if (aff) { x32_affine(x, t32_load(aff + ((size_t)l * B + at.b) * 64, q)); x32_mask(x, mk); }
       W32 w;
 #pragma unroll
       for (int ci = 0; ci < 2; ++ci)
@@ -1145,10 +1216,11 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
     if (prof) prof_before(c.st);
     hipLaunchKernelGGL(mlp32w_fwd_kernel, dim3(wide32_grid(c.B, c.P)), dim3(256), 0, c.st, x, x_bs, (const float*)q.m1_w0, (const float*)q.m2_w0,
                        (const float*)q.m1_w1, (const float*)q.m2_w1, (const float*)q.m1_b0, (const float*)q.m2_b0, (const float*)q.m1_b1, (const float*)q.m2_b1,
-                       maskp, o1, o2, save_hid ? hid1 : (float*)nullptr, save_hid ? hid2 : (float*)nullptr, hs, c.P, c.B);
+                       maskp, o1, o2, save_hid ? hid1 : (float*)nullptr, save_hid ? hid2 : (float*)nullptr, hs, c.P, c.B, aff);
     if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 8.0 * 32 * 32 * (double)c.P * c.B, (save_hid ? 5.0 : 3.0) * sizeof(float) * 32 * (double)c.P * c.B);
     return check_launch("mlp32w_fwd");
   }
+  if (aff) return fail(DPPM_E_INVALID, "mlp_pair: a folded instance norm needs the weight-stationary kernels");
   if (H == 32 && !mlp32_off) {   // hidden-32 networks: both MLPs of the layer in one streaming launch
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
@@ -1390,6 +1462,10 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
                          (sw(SW_DISABLE_W4) == 0 ||     // the forms of dppm_wsplit.h keep per-graph tables in LDS
                           (w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(2, (long)B * tpp))) &&
                            w3_contig_ok((long)B * tpp, tpp, (int)(8 * w3_slots(1, (long)B * tpp)))));
+  // hidden 32, N > 20 (the wide kernels): the same folding in exact f32 -- lin32x2w_kernel leaves the raw result + group statistics,
+  // mlp32w / lin32x2w / head32w apply the (scale, shift) tables to their sources
+  const bool fuse32 = H == 32 && !training && !pr->layer_cond && sw(SW_DISABLE_NORMFUSE) == 0 && sw(SW_DISABLE_MLP32) == 0 && sw(SW_DISABLE_WIDE32) == 0 &&
+                      P % 4 == 0 && L <= H32_MAXL;
   // in_lin (K = 2) folded into layer 0's consumers: u0 is never written (one plane-set less to write, two less to read per level)
   const bool fuse_inlin = fuse_norm && sw(SW_DISABLE_W4) == 0 && sw(SW_DISABLE_INLINFUSE) == 0;
   const InlSrc inl{pr->in_w, pr->in_b, cat, cat_bs};
@@ -1398,8 +1474,8 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     hipLaunchKernelGGL(inlin_kernel, dim3(cdiv(P, 1024), B), dim3(256), 0, c.st, cat, cat_bs, pr->in_w, pr->in_b, H, P, c.at(w.u0));
     DPPM_TRY(check_launch("in_lin"));
   }
-  float* naff = fuse_norm ? c.at(w.naff) : nullptr;
-  const size_t aff_sz = (size_t)B * 2 * WS_H;
+  float* naff = (fuse_norm || fuse32) ? c.at(w.naff) : nullptr;
+  const size_t aff_sz = (size_t)B * 2 * H;
   if (fuse_norm) {
     hipLaunchKernelGGL(aff_identity_kernel, dim3(cdiv((long)aff_sz, 256)), dim3(256), 0, c.st, naff + (size_t)L * aff_sz, (int)aff_sz);
     DPPM_TRY(check_launch("aff_identity"));
@@ -1420,7 +1496,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       DPPM_TRY(check_launch("diag_set"));
     }
     DPPM_TRY(mlp_pair(Geo{B, P, c.st}, q, H, x, x_bs, maskp, o1, o2, hid1, hid2, training != 0, prec,
-                      fuse_norm && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr, fuse_inlin && l == 0 ? &inl : nullptr));
+                      (fuse_norm || fuse32) && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr, fuse_inlin && l == 0 ? &inl : nullptr));
     // per-channel contraction / sqrt(n)   (model/ppgn.py:62-64)
     DPPM_TRY(plane_mm(c.st, o1, o2, mm, B * H, N, w.ld, false, false, c.at(w.inv_norm), nullptr, H, training ? DPPM_PREC_F32X6 : prec));
     // m4 on cat(mm, x)   (model/ppgn.py:66-69)
@@ -1447,7 +1523,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       DPPM_TRY(ws_lin_p(wa, 2, false, prec, c.st));
       if (fuse_norm) {
         hipLaunchKernelGGL(norm_finalize_kernel, dim3(B * (WS_H / NF_CH)), dim3(NF_CH * NF_GRP), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,
-                           naff + (size_t)l * aff_sz);
+                           naff + (size_t)l * aff_sz, WS_H);
         DPPM_TRY(check_launch("norm_finalize"));
         if (wa.dbg & 4) {
           launch_inorm_fwd(P, B * H, c.st, (const float*)(cat + (size_t)(2 + l * H) * P), cat_bs, (const float*)maskp, y, hs, H, P, c.at(w.nstat), c.at(w.nstat) + B * H);
@@ -1457,13 +1533,23 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
         continue;
       }
     } else if (H == 32 && wide32_ok(P, mm, hs, y, hs) && aligned16(x) && x_bs % 4 == 0) {
+      if (fuse32 && !aligned16(maskp)) return fail(DPPM_E_INVALID, "dppm_ppgn_forward: mask planes must be 16-byte aligned");
       const bool prof = prof_enabled();
       if (prof) prof_before(c.st);
+      float* yo = fuse32 ? cat + (size_t)(2 + l * H) * P : y;   // fuse32: the raw result straight into the CAT slot, statistics beside it
       hipLaunchKernelGGL(lin32x2w_kernel, dim3(wide32_grid(B, P)), dim3(256), 0, c.st, (const float*)q.m4_w, 2 * H, (const float*)q.m4_b, (const float*)mm, hs,
-                         x, x_bs, y, hs, P, B);
+                         x, x_bs, yo, fuse32 ? cat_bs : hs, P, B, (const float*)(fuse32 && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr), (const float*)maskp,
+                         fuse32 ? c.at(w.nstat) : (float*)nullptr, fuse32 ? c.at(w.ncnt) : (float*)nullptr);
       if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 4.0 * 32 * 32 * (double)P * B, 3.0 * sizeof(float) * 32 * (double)P * B);
       DPPM_TRY(check_launch("lin32x2w"));
+      if (fuse32) {
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3(B * (H / NF_CH)), dim3(NF_CH * NF_GRP), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,
+                           naff + (size_t)l * aff_sz, H);
+        DPPM_TRY(check_launch("norm_finalize"));
+        continue;
+      }
     } else {
+      if (fuse32) return fail(DPPM_E_INVALID, "dppm_ppgn_forward: the folded instance norm of the hidden-32 path needs the wide kernels");
       LinArgs sx{q.m4_w + H, 2 * H, false, x, x_bs, H};
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w, 2 * H, false, mm, hs, H}, &sx, q.m4_b, 0, nullptr, nullptr, 0, y, hs, false));
     }
@@ -1481,6 +1567,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
                 logits, B, N, w.ld, P, L, fuse_norm ? naff : nullptr, fuse_norm ? maskp : nullptr};
     return head3_run(ha, pr->after_w, prec == DPPM_PREC_BF16X3 ? 3 : 1, c.st);
   }
+  if (fuse32 && !(wide32_ok(P, cat, cat_bs, c.at(w.R), hs) && aligned16(c.at(w.act)))) return fail(DPPM_E_INVALID, "dppm_ppgn_forward: hidden-32 read-out: alignment");
   if (H == 32 && L <= H32_MAXL && wide32_ok(P, cat, cat_bs, c.at(w.R), hs) && aligned16(c.at(w.act))) {   // hidden-32 read-out in one pass
     const size_t lds = (size_t)(2 + 32 * L) * 33 * sizeof(float);
     DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&head32w_kernel), lds, "head32w"));
@@ -1489,7 +1576,8 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
     const int grid = wide32_grid(B, P) < 512 ? wide32_grid(B, P) : 512;   // every block stages the weights once
     hipLaunchKernelGGL(head32w_kernel, dim3(grid), dim3(256), lds, c.st, (const float*)cat, cat_bs, (const float*)pr->cat_w, w.CT, (const float*)pr->cat_b,
                        (const float*)pr->after_w, (const float*)pr->after_b, (const float*)pr->final_w, (const float*)pr->final_b,
-                       training ? c.at(w.R) : (float*)nullptr, training ? c.at(w.act) : (float*)nullptr, hs, logits, N, w.ld, L, B);
+                       training ? c.at(w.R) : (float*)nullptr, training ? c.at(w.act) : (float*)nullptr, hs, logits, N, w.ld, L, B,
+                       (const float*)(fuse32 ? naff : nullptr), (const float*)maskp);
     if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 2.0 * 32 * ((double)w.CT + 32 + 1) * P * B,
                          sizeof(float) * ((double)w.CT * P + (training ? 64.0 * P : 0.0) + (double)N * N) * B);
     return check_launch("head32w");

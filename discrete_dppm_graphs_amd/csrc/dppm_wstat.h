@@ -237,12 +237,14 @@ __device__ __forceinline__ void ws_store_wide(floatx4 (&acc)[4], float* __restri
 // of vector issue slots rather than of LDS cycles.  bias: the lane's channel ch0 + ci.  The pitch keeps both the b128 stores (8
 // lanes of one g, rows ci .. ci+7) and the b128 loads (16 lanes along a row) free of bank conflicts.
 constexpr int WS_WIDE_PITCH = 68;
+template <bool ADDB = true>   // ADDB = false: the accumulators already hold the bias
 __device__ __forceinline__ void ws_store_wide_lds(const floatx4 (&acc)[4], float* __restrict__ R, float* __restrict__ Yt, int ch0, int P, float bias,
                                                   const float* __restrict__ Mt, int lim, int lane) {
   const int ci = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    *reinterpret_cast<float4*>(R + ci * WS_WIDE_PITCH + 16 * j + 4 * g) = make_float4(acc[j][0] + bias, acc[j][1] + bias, acc[j][2] + bias, acc[j][3] + bias);
+    *reinterpret_cast<float4*>(R + ci * WS_WIDE_PITCH + 16 * j + 4 * g) =
+        ADDB ? make_float4(acc[j][0] + bias, acc[j][1] + bias, acc[j][2] + bias, acc[j][3] + bias) : make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   const int pos = 4 * ci;
   float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
   if (Mt) m = *reinterpret_cast<const float4*>(Mt + pos);

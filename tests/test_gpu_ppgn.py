@@ -97,6 +97,13 @@ def test_hidden32_wide_kernels(ops, B, N, L):
     close(got, ref)
     close(got, old, tol=2e-5)
     assert not np.array_equal(got, old) or N < 8      # the switch did select other kernels (different summation order)
+    # inference folds the instance norm into m4 (group statistics) and its consumers, as the H = 128 path does; against the stand-alone pass
+    with ops.debug_switch(DISABLE_NORMFUSE=1):
+        unf, _ = run_gpu(ops, W, A, mask, sigma, L, H)
+    close(got, unf, tol=2e-5)
+    assert not np.array_equal(got, unf)
+    again, _ = run_gpu(ops, W, A, mask, sigma, L, H)
+    assert np.array_equal(got, again)
     R = rng.normal(size=A.shape).astype(np.float32) * mask
     lg, g = run_gpu(ops, W, A, mask, sigma, L, H, dlogits=R)
     with ops.debug_switch(DISABLE_WIDE32=1):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kstat.sh <file.hip> <kernel-name-regex>   -> VGPRs / spills / scratch of matching kernels (gfx950); EXTRA="-D..." adds flags
 cd "$(dirname "$0")/../discrete_dppm_graphs_amd/csrc" || exit 1
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include -I. ${EXTRA} -c "$1" -o "/tmp/kstat_$$.o" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -I../../include -I. ${EXTRA} -c "$1" -o "/tmp/kstat_$$.o" \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys, re
 pat = re.compile(sys.argv[1]); cur = None; rows = {}
