@@ -120,7 +120,9 @@ int dppm_loss_bce_fwd_bwd(const float* score, const float* target, const double*
  * library (256 KiB per GPU, held until the process ends) instead of a caller workspace; the call makes no hipMalloc / hipFree /
  * allocating library call.  At most DPPM_NOALLOC_MAX_GRAPHS graphs per call (more: DPPM_E_INVALID, use the entry point above).
  * All calls on one GPU share that array: calls that overlap on one GPU (different streams, or threads) race; calls on one stream
- * are ordered and safe.  Results are bit-identical to dppm_loss_bce_fwd_bwd. */
+ * are ordered and safe.  Results are bit-identical to dppm_loss_bce_fwd_bwd.
+ * The FIRST call on each device looks up the array's device address (hipGetSymbolAddress, once per device, under a mutex): that lookup
+ * is not a capturable operation, so make one call on the device before a stream capture begins; every later call only launches kernels. */
 #define DPPM_NOALLOC_MAX_GRAPHS 4096
 int dppm_loss_bce_fwd_bwd_noalloc(const float* score, const float* target, const double* sigma_dev, const float* mask,
                                   int B, int N, int B_global, double* loss_out, float* dscore, void* stream);
