@@ -37,6 +37,9 @@ __device__ unsigned long long g_w4_trace[3 * 3 * 256];
 #ifndef W4_PKEPI
 #define W4_PKEPI 0
 #endif
+#ifndef W4_SKEW
+#define W4_SKEW 0
+#endif
 #ifndef W4_BIASINIT
 #define W4_BIASINIT 0   // experiment, off: both products' accumulators start from the bias (64 of ~550 vector instructions per tile and SIMD less):
                         // 0.4868 -> 0.4817 ms, and the headline distance to float64 goes from 1.01e-4 to 1.30e-4 -- not worth a new rounding order
@@ -534,6 +537,35 @@ __global__ __launch_bounds__(64 * (STG + 8)) void w4_mlp_kernel(const WsArgs a) 
   // group's MFMAs; repeated in round 3 with the packed-f32 operations taken out of the epilogue, -fno-slp-vectorize: 0.523 against
   // 0.494 ms); s_setprio for either role changed nothing; both channel blocks through the patch behind ONE wait (block 1 written as
   // soon as block 0's reads are issued, eight stores in a row) was slower too: 0.549 against 0.515 ms.
+#if W4_SKEW
+  // Experiment: the second product's stores one interval late, so that on every SIMD this wave's vector work (DPP transposition, bias,
+  // mask, stores: no LDS) runs beside the first product's MFMAs and its MFMAs beside the first product's epilogue -- matrix beside
+  // vector instead of matrix beside matrix (MI355X_MICROARCH.md, "Two waves per SIMD").  The accumulators live across one barrier.
+  {
+    const float4 bw[2] = {ws_bias_wide(J.b2, 32 * pw, lane), ws_bias_wide(J.b2, 32 * pw + 16, lane)};
+    floatx4 acc[2][4];
+    auto out = [&](int k) {                                  // tile k of this workgroup leaves
+      const int t = who.rank + k * who.per_job;
+      const int b = __builtin_amdgcn_readfirstlane(t / tpp), p0 = __builtin_amdgcn_readfirstlane((t - b * tpp) * WS_TP);
+      float* Yt = J.Y + (size_t)b * J.y_bs + p0;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) ws_store_wide(acc[cb], Yt, 32 * pw + 16 * cb, P, &bw[cb], Ms + (k & 3) * 64, P - p0, lane, false, false);
+    };
+    for (int i = 0; i <= nloc; ++i) {
+      if (i >= 2) out(i - 2);
+      if (i >= 1) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[cb][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        w4_mma8<NS, false>(acc, wh, wl, Hs + ((i - 1) & 1) * BUF, ad);
+      }
+      __syncthreads();
+    }
+    out(nloc - 1);
+    return;
+  }
+#endif
   float b2v[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) b2v[cb] = J.b2 ? J.b2[32 * pw + 16 * cb + ci] : 0.f;
