@@ -76,7 +76,8 @@ __global__ __launch_bounds__(768) void probe(const float4* __restrict__ X, const
     affine2<MODE>(p.c, floatx2{sc.x, sc.y}, floatx2{sh.x, sh.y}); affine2<MODE>(p.d, floatx2{sc.z, sc.w}, floatx2{sh.z, sh.w});
     affine2<MODE>(q.a, floatx2{sc2.x, sc2.y}, floatx2{sh2.x, sh2.y}); affine2<MODE>(q.b, floatx2{sc2.z, sc2.w}, floatx2{sh2.z, sh2.w});
     affine2<MODE>(q.c, floatx2{sc2.x, sc2.y}, floatx2{sh2.x, sh2.y}); affine2<MODE>(q.d, floatx2{sc2.z, sc2.w}, floatx2{sh2.z, sh2.w});
-    if (li < nloc) {
+    {   // (unconditional straight-line code: a load or store behind a loop-dependent branch makes hipcc drain the queue with vmcnt(0)
+        // in front of the packed instructions, and then nothing is in flight while they execute)
       float4* Yt = Y + (size_t)t * 2048 + tid;
       Yt[0] = p.a; Yt[256] = p.b; Yt[512] = p.c; Yt[768] = p.d; Yt[1024] = q.a; Yt[1280] = q.b; Yt[1536] = q.c; Yt[1792] = q.d;
     }
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(768) void probe(const float4* __restrict__ X, const
   __syncthreads();
   Pre p0, q0, p1, q1, p2, q2;
   issue(p0, q0); issue(p1, q1); issue(p2, q2);
-  for (int i = 0; i < nloc; i += 3) {
-    if (i < nloc) { land(p0, q0); issue(p0, q0); __syncthreads(); }
-    if (i + 1 < nloc) { land(p1, q1); issue(p1, q1); __syncthreads(); }
-    if (i + 2 < nloc) { land(p2, q2); issue(p2, q2); __syncthreads(); }
+  for (int i = 0; i < nloc; i += 3) {                        // nloc % 3 == 0 (host)
+    land(p0, q0); issue(p0, q0); __syncthreads();
+    land(p1, q1); issue(p1, q1); __syncthreads();
+    land(p2, q2); issue(p2, q2); __syncthreads();
   }
 }
 
@@ -102,7 +103,7 @@ template <int MODE> static void run(const float4* X, const float* T, float4* Y, 
 
 int main(int argc, char** argv) {
   const int repeats = argc > 1 ? atoi(argv[1]) : 20;
-  const int ntiles = 16384;                                  // x 32 KB = 512 MB
+  const int ntiles = 256 * 63;                               // x 32 KB = 504 MB; 63 tiles per workgroup
   const size_t nx = (size_t)ntiles * 2048;
   std::vector<float4> h(nx);
   unsigned s = 777;
@@ -114,10 +115,33 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(X, h.data(), nx * sizeof(float4), hipMemcpyHostToDevice); (void)hipMemcpy(T, ht.data(), ht.size() * sizeof(float), hipMemcpyHostToDevice);
   std::vector<float4> a(nx), b(nx);
   unsigned long long bad_hi = 0, bad_lo = 0, bad_scalar = 0;
+  int shown = 0;
   for (int r = 0; r < repeats; ++r) {
     run<1>(X, T, Y1, ntiles); (void)hipDeviceSynchronize(); (void)hipMemcpy(b.data(), Y1, nx * sizeof(float4), hipMemcpyDeviceToHost);
     run<0>(X, T, Y0, ntiles); (void)hipDeviceSynchronize(); (void)hipMemcpy(a.data(), Y0, nx * sizeof(float4), hipMemcpyDeviceToHost);
-    for (size_t i = 0; i < nx; ++i) bad_hi += memcmp(&a[i], &b[i], 16) != 0;
+    for (size_t i = 0; i < nx; ++i)
+      if (memcmp(&a[i], &b[i], 16) != 0) {
+        ++bad_hi;
+        // which registers did the instruction compute with?  float4 i = tile t, slot k (row), thread tid; its channel pair of the table
+        const size_t t = i / 2048; const int k = (int)((i % 2048) / 256), tid = (int)(i % 256), cg = tid >> 4;
+        const int g = (int)(t % 256), li = (int)(t / 256);                 // workgroup, its li-th tile
+        const int trow = li == 0 ? g % 64 : (int)((g + (size_t)(li - 1) * 256 + 256) % 64);   // the table the tile saw (see the kernel)
+        const int ch = 4 * cg + (k >= 4 ? 64 : 0) + ((k & 1) ? 2 : 0);      // the pair's LOW channel; the form uses ch + 1
+        const float* T = &ht[(size_t)trow * 256];
+        const float scl = T[ch], sch = T[ch + 1], shl = T[128 + ch], shh = T[128 + ch + 1];
+        const float x[4] = {h[i].x, h[i].y, h[i].z, h[i].w}, got[4] = {a[i].x, a[i].y, a[i].z, a[i].w}, want[4] = {b[i].x, b[i].y, b[i].z, b[i].w};
+        if (shown < 6 || (bad_hi % 64 == 1 && shown < 16)) {
+          ++shown;
+          printf("  repeat %d tile %zu row %d thread %3d:", r, t, k, tid);
+          for (int e = 0; e < 4; ++e) {
+            const char* how = got[e] == want[e] ? "ok" : got[e] == fmaf(x[e], scl, shl) ? "LOW scale, LOW shift" : got[e] == fmaf(x[e], scl, shh) ? "LOW scale" :
+                              got[e] == fmaf(x[e], sch, shl) ? "LOW shift" : "other";
+            printf(" [%d] %s", e, how);
+          }
+          printf("\n      x = %.6g %.6g  got %.9g want %.9g | scale lo %.6g hi %.6g shift lo %.6g hi %.6g | (got - shift_hi) / x = %.6g, (got - shift_lo) / x = %.6g, (got - want) = %.6g\n",
+                 x[0], x[1], got[0], want[0], scl, sch, shl, shh, (got[0] - shh) / x[0], (got[0] - shl) / x[0], got[0] - want[0]);
+        }
+      }
     run<1>(X, T, Y0, ntiles); (void)hipDeviceSynchronize(); (void)hipMemcpy(a.data(), Y0, nx * sizeof(float4), hipMemcpyDeviceToHost);
     for (size_t i = 0; i < nx; ++i) bad_scalar += memcmp(&a[i], &b[i], 16) != 0;
     run<3>(X, T, Y1, ntiles); (void)hipDeviceSynchronize(); (void)hipMemcpy(b.data(), Y1, nx * sizeof(float4), hipMemcpyDeviceToHost);
