@@ -5,6 +5,10 @@
 // fragments and run MFMAs.  MODE 0 writes the packed form's results, MODE 1 the same arithmetic as two v_fma_f32, MODE 2 the packed form
 // with the LOW register broadcast (op_sel_hi:[1,0,0]; compared with its own scalar twin, MODE 3); the host compares the outputs.
 // build: hipcc -O3 --offload-arch=gfx950 -o tools/dbg/pk_opsel_probe3 tools/dbg/pk_opsel_probe3.hip     run: tools/dbg/pk_opsel_probe3 [repeats]
+#ifndef PARTNER
+#define PARTNER 2   // what the eight other waves do between barriers: 0 nothing, 1 LDS reads, 2 LDS reads + MFMAs (compile-time: the effect is
+                    // sensitive to the partner waves' timing -- with this as a run-time branch the probe found 0 of 2.6e9)
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -44,12 +48,18 @@ __global__ __launch_bounds__(768) void probe(const float4* __restrict__ X, const
     floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     __syncthreads();
     for (int i = 0; i < nloc; ++i) {
+#if PARTNER
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const uintx4 v = *reinterpret_cast<const volatile uintx4*>(base + ((k * 1024 + i * 8192) & 65535));
+#if PARTNER == 2
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, v), acc[j], 0, 0, 0);
+#else
+        acc[k & 3][0] += __uint_as_float(v[0]);
+#endif
       }
+#endif
       __syncthreads();
     }
     if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 12345.678f) Y[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,7 +140,7 @@ int main(int argc, char** argv) {
         const float* T = &ht[(size_t)trow * 256];
         const float scl = T[ch], sch = T[ch + 1], shl = T[128 + ch], shh = T[128 + ch + 1];
         const float x[4] = {h[i].x, h[i].y, h[i].z, h[i].w}, got[4] = {a[i].x, a[i].y, a[i].z, a[i].w}, want[4] = {b[i].x, b[i].y, b[i].z, b[i].w};
-        if (shown < 6 || (bad_hi % 64 == 1 && shown < 16)) {
+        if (shown < 3) {
           ++shown;
           printf("  repeat %d tile %zu row %d thread %3d:", r, t, k, tid);
           for (int e = 0; e < 4; ++e) {
