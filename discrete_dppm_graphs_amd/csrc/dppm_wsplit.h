@@ -221,7 +221,9 @@ __device__ __forceinline__ unsigned w3_off(const W3Addr& a, int j, int s) { retu
 // (op_sel:[0,1] op_sel_hi:[1,0]) in waves that keep vector-memory loads in flight beside other waves' MFMAs: the in_lin rows of
 // w4_mlp_kernel's stagers (operands: destination pairs of global loads) and the side-input term of head3_kernel's epilogue (operands:
 // LDS reads, the next weight fragments in flight; round 2's global-load form of it was only deterministic behind a vmcnt(0)).
-// Every build of either kernel without those packed forms is bit-exact and deterministic ("The in_lin stagers").
+// Every build of either kernel without those packed forms is bit-exact and deterministic.  Reproduced outside the library
+// (tools/dbg/pk_opsel_probe3.hip): a packed-f32 instruction with an op_sel bit set loses the product of its low half -- the result is the
+// addend alone -- now and then while the wave has loads in flight and another wave of the SIMD runs MFMAs.
 // -DW3_SIDE_PACKED gives the expression back to the compiler for that experiment (tools/dbg/head_packed_ab.sh).
 __device__ __forceinline__ float w3_side_s(float w0, float w1, float bc, float a, float s) {
 #ifdef W3_SIDE_PACKED
