@@ -94,8 +94,8 @@ def test_no_packed_f32_operand_selects_anywhere(kernels):
     seen = 0
     for m in re.finditer(r"<(_Z\w+)>:\n(.*?)(?=\n\n|\Z)", dis, re.S):
         seen += 1
-        hits = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*op_sel:\[[0-9,]*1[^\n]*", m.group(2))
-        assert not hits, f"{m.group(1)}: {len(hits)} packed-f32 instructions select a high register for the low half, e.g. {hits[0]}"
+        hits = re.findall(r"v_\w+[^\n]*op_sel:\[[0-9,]*1[^\n]*", m.group(2))   # any VOP3P instruction, packed f32 or not
+        assert not hits, f"{m.group(1)}: {len(hits)} instructions select a high register for the low half, e.g. {hits[0]}"
         if re.search(r"w4_mlp_kernelILi3|w4_lin2_kernelILi3|head3_kernelILi3|plane4_kernelILi\d+ELi3", m.group(1)):
             hits = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*op_sel[^\n]*", m.group(2))
             assert not hits, f"{m.group(1)}: {len(hits)} packed-f32 instructions with operand-half selects, e.g. {hits[0]}"
