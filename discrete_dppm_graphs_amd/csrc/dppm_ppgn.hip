@@ -931,7 +931,99 @@ __global__ __launch_bounds__(256) void mlp32w_fwd_kernel(const float* __restrict
   }
 }
 
+// The same pair in split-bf16 arithmetic (inference, precision bf16x3): K = 32 is ONE k step of v_mfma_f32_16x16x32_bf16.  With k slot e of
+// lane group q standing for channel (e < 4 ? 4 q + e : 16 + 4 q + e - 4), the eight values a lane holds for a position -- loaded float4s,
+// or the first product's result in the MFMA layout -- are exactly its B fragment, and the weights are fragmented in that order once.
+// Three MFMAs per product (hi hi + hi lo + lo hi, as in the H = 128 kernels): 24 MFMAs of 16 cycles per product and 64 positions in
+// place of 64 of 32 cycles.
+struct W32S { uintx4 h[2], l[2]; };                          // [co]: A fragment of output block co (hi / lo pieces)
+__device__ __forceinline__ W32S w32s_load(const float* __restrict__ W, int ldw, int q, int n) {
+  W32S f;
+#pragma unroll
+  for (int co = 0; co < 2; ++co) {
+    const float* row = W + (size_t)(16 * co + n) * ldw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = row[(e < 4 ? 4 * q + e : 16 + 4 * q + e - 4)];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { unsigned h, l = 0; w3_split2<3>(v[2 * e], v[2 * e + 1], h, l); f.h[co][e] = h; f.l[co][e] = l; }
+  }
+  return f;
+}
+__device__ __forceinline__ void b32s_split(const float (&v)[8], uintx4& h, uintx4& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { unsigned hh, ll = 0; w3_split2<3>(v[2 * e], v[2 * e + 1], hh, ll); h[e] = hh; l[e] = ll; }
+}
+__device__ __forceinline__ void a32s_mma(A32& a, const W32S& w, int j, const uintx4& bh, const uintx4& bl) {
+#pragma unroll
+  for (int co = 0; co < 2; ++co) {
+    a.a[j][co] = w3_mfma(w.h[co], bl, a.a[j][co]);
+    a.a[j][co] = w3_mfma(w.l[co], bh, a.a[j][co]);
+    a.a[j][co] = w3_mfma(w.h[co], bh, a.a[j][co]);
+  }
+}
+__global__ __launch_bounds__(256) void mlp32w3_fwd_kernel(const float* __restrict__ X, long x_bs,
+                                                          const float* __restrict__ W0a, const float* __restrict__ W0b,
+                                                          const float* __restrict__ W1a, const float* __restrict__ W1b,
+                                                          const float* __restrict__ b0a, const float* __restrict__ b0b,
+                                                          const float* __restrict__ b1a, const float* __restrict__ b1b,
+                                                          const float* __restrict__ maskp, float* __restrict__ o1, float* __restrict__ o2,
+                                                          long hs, int P, int B, const float* __restrict__ aff) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int gpp = (P + 63) >> 6, ngroups = B * gpp;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
+  const W32S w0a = w32s_load(W0a, 32, q, n), w0b = w32s_load(W0b, 32, q, n), w1a = w32s_load(W1a, 32, q, n), w1b = w32s_load(W1b, 32, q, n);
+  if (wave0 >= ngroups) return;
+  G32 nx = g32_of(wave0, gpp, P, n);
+  X32 xn = x32_load(X + (size_t)nx.b * x_bs + nx.p0, P, q, n, nx.ok);
+  for (int g = wave0; g < ngroups; g += nwaves) {
+    const G32 at = nx;
+    X32 x = xn;
+    if (g + nwaves < ngroups) {
+      nx = g32_of(g + nwaves, gpp, P, n);
+      xn = x32_load(X + (size_t)nx.b * x_bs + nx.p0, P, q, n, nx.ok);
+    }
+    if (aff) x32_affine(x, t32_load(aff + (size_t)at.b * 64, q));
+    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (maskp && at.ok) mk = *reinterpret_cast<const float4*>(maskp + (size_t)at.b * P + at.p0 + 4 * n);
+    uintx4 xh[4], xl[4];                                     // the source's fragments, one per tile j, shared by both MLPs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f4_at(x.v[e >> 2][e & 3], j);
+      b32s_split(v, xh[j], xl[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      A32 t, acc;
+      a32_zero(t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a32s_mma(t, k ? w0b : w0a, j, xh[j], xl[j]);
+      a32_bias(t, k ? b0b : b0a, q);
+      a32_leaky(t);
+      a32_zero(acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t.a[j][e >> 2][e & 3];
+        uintx4 th, tl;
+        b32s_split(v, th, tl);
+        a32s_mma(acc, k ? w1b : w1a, j, th, tl);
+      }
+      a32_bias(acc, k ? b1b : b1a, q);
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc.a[0][co][r] *= mk.x; acc.a[1][co][r] *= mk.y; acc.a[2][co][r] *= mk.z; acc.a[3][co][r] *= mk.w; }
+      a32_store(acc, (k ? o2 : o1) + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
+    }
+  }
+}
+
 // m4 of a hidden-32 layer on cat(mm, x) (model/ppgn.py:66-69): Y = W[:, 0:32] mm + W[:, 32:64] x + b, both halves resident (32 registers)
+template <bool SPLIT>   // SPLIT: both products as three bf16 MFMAs on split operands (inference, precision bf16x3), as mlp32w3_fwd_kernel
 __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
                                                        const float* __restrict__ X1, long x1_bs, const float* __restrict__ X2, long x2_bs,
                                                        float* __restrict__ Y, long y_bs, int P, int B,
@@ -942,7 +1034,10 @@ __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int gpp = (P + 63) >> 6, ngroups = B * gpp;
   const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
-  const W32 wa = w32_load(W, ldw, q, n), wb = w32_load(W + 32, ldw, q, n);
+  W32 wa{}, wb{};
+  W32S sa{}, sb{};
+  if (SPLIT) { sa = w32s_load(W, ldw, q, n); sb = w32s_load(W + 32, ldw, q, n); }
+  else { wa = w32_load(W, ldw, q, n); wb = w32_load(W + 32, ldw, q, n); }
   if (wave0 >= ngroups) return;
   G32 nx = g32_of(wave0, gpp, P, n);
   X32 x1n = x32_load(X1 + (size_t)nx.b * x1_bs + nx.p0, P, q, n, nx.ok), x2n = x32_load(X2 + (size_t)nx.b * x2_bs + nx.p0, P, q, n, nx.ok);
@@ -958,8 +1053,24 @@ __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__
     if (aff2) x32_affine(x2, t32_load(aff2 + (size_t)at.b * 64, q));
     A32 acc;
     a32_zero(acc);
-    a32_mma(acc, wa, x1);
-    a32_mma(acc, wb, x2);
+    if (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8];
+        uintx4 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f4_at(x1.v[e >> 2][e & 3], j);
+        b32s_split(v, h, l);
+        a32s_mma(acc, sa, j, h, l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f4_at(x2.v[e >> 2][e & 3], j);
+        b32s_split(v, h, l);
+        a32s_mma(acc, sb, j, h, l);
+      }
+    } else {
+      a32_mma(acc, wa, x1);
+      a32_mma(acc, wb, x2);
+    }
     a32_bias(acc, bias, q);
     if (stat) {
       const float4 mk = at.ok ? *reinterpret_cast<const float4*>(maskp + (size_t)at.b * P + at.p0 + 4 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1214,6 +1325,13 @@ int mlp_pair(const Geo& c, const dppm_ppgn_layer& q, int H, const float* x, long
       (!save_hid || (aligned16(hid1) && aligned16(hid2)))) {   // 64 positions per wave, 16-byte accesses
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
+    if (!save_hid && prec == DPPM_PREC_BF16X3 && sw(SW_DISABLE_MLP32S) == 0) {   // inference in the split arithmetic
+      hipLaunchKernelGGL(mlp32w3_fwd_kernel, dim3(wide32_grid(c.B, c.P)), dim3(256), 0, c.st, x, x_bs, (const float*)q.m1_w0, (const float*)q.m2_w0,
+                         (const float*)q.m1_w1, (const float*)q.m2_w1, (const float*)q.m1_b0, (const float*)q.m2_b0, (const float*)q.m1_b1, (const float*)q.m2_b1,
+                         maskp, o1, o2, hs, c.P, c.B, aff);
+      if (prof) prof_after(c.st, PROF_LINEAR, AR_BF16X3, 8.0 * 32 * 32 * (double)c.P * c.B, 3.0 * sizeof(float) * 32 * (double)c.P * c.B);
+      return check_launch("mlp32w3_fwd");
+    }
     hipLaunchKernelGGL(mlp32w_fwd_kernel, dim3(wide32_grid(c.B, c.P)), dim3(256), 0, c.st, x, x_bs, (const float*)q.m1_w0, (const float*)q.m2_w0,
                        (const float*)q.m1_w1, (const float*)q.m2_w1, (const float*)q.m1_b0, (const float*)q.m2_b0, (const float*)q.m1_b1, (const float*)q.m2_b1,
                        maskp, o1, o2, save_hid ? hid1 : (float*)nullptr, save_hid ? hid2 : (float*)nullptr, hs, c.P, c.B, aff);
@@ -1537,10 +1655,12 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
       const bool prof = prof_enabled();
       if (prof) prof_before(c.st);
       float* yo = fuse32 ? cat + (size_t)(2 + l * H) * P : y;   // fuse32: the raw result straight into the CAT slot, statistics beside it
-      hipLaunchKernelGGL(lin32x2w_kernel, dim3(wide32_grid(B, P)), dim3(256), 0, c.st, (const float*)q.m4_w, 2 * H, (const float*)q.m4_b, (const float*)mm, hs,
+      const bool split32 = !training && prec == DPPM_PREC_BF16X3 && sw(SW_DISABLE_MLP32S) == 0;
+      hipLaunchKernelGGL(split32 ? lin32x2w_kernel<true> : lin32x2w_kernel<false>, dim3(wide32_grid(B, P)), dim3(256), 0, c.st, (const float*)q.m4_w, 2 * H,
+                         (const float*)q.m4_b, (const float*)mm, hs,
                          x, x_bs, yo, fuse32 ? cat_bs : hs, P, B, (const float*)(fuse32 && l > 0 ? naff + (size_t)(l - 1) * aff_sz : nullptr), (const float*)maskp,
                          fuse32 ? c.at(w.nstat) : (float*)nullptr, fuse32 ? c.at(w.ncnt) : (float*)nullptr);
-      if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 4.0 * 32 * 32 * (double)P * B, 3.0 * sizeof(float) * 32 * (double)P * B);
+      if (prof) prof_after(c.st, PROF_LINEAR, split32 ? AR_BF16X3 : AR_F32, 4.0 * 32 * 32 * (double)P * B, 3.0 * sizeof(float) * 32 * (double)P * B);
       DPPM_TRY(check_launch("lin32x2w"));
       if (fuse32) {
         hipLaunchKernelGGL(norm_finalize_kernel, dim3(B * (H / NF_CH)), dim3(NF_CH * NF_GRP), 0, c.st, (const float*)c.at(w.nstat), (const float*)c.at(w.ncnt), tpp,

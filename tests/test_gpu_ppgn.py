@@ -115,6 +115,31 @@ def test_hidden32_wide_kernels(ops, B, N, L):
         assert np.abs(g[k] - g0[k]).max() <= 3e-3 * max(np.abs(g0[k]).max(), 2e-2 * gmax), k
 
 
+@pytest.mark.parametrize("B,N,L", [(3, 41, 3), (2, 200, 6), (1, 23, 16)])
+def test_hidden32_split_mlp(ops, B, N, L):
+    """Hidden-32 inference in precision bf16x3: the MLP pair of the wide kernels runs as three bf16 MFMAs per product on split operands
+    (mlp32w3_fwd_kernel; m4, the contraction's split form and the read-out as before).  Held to the north star's 1e-3 of max |logit|
+    against the oracle; the measured distance is printed.  DISABLE_MLP32S selects the exact-f32 pair for the same call."""
+    from oracle import ppgn as op
+    H = 32
+    rng = np.random.default_rng(7100 + N + L)
+    A, mask = rand_case(rng, B, N)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, H, seed=N + 17 * L)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    with ops.debug_switch(DISABLE_MLP32S=1):
+        exact, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    scale = np.abs(ref).max()
+    print(f"\nhidden-32 bf16x3 N={N} L={L}: split MLP {np.abs(got - ref).max() / scale:.2e}, exact-f32 MLP {np.abs(exact - ref).max() / scale:.2e} of max |logit|")
+    close(got, ref, tol=1e-3)
+    close(exact, ref, tol=1e-3)
+    assert not np.array_equal(got, exact)
+    again, _ = run_gpu(ops, W, A, mask, sigma, L, H, precision="bf16x3")
+    assert np.array_equal(got, again)
+
+
 @pytest.mark.parametrize("B,N,H,L", [(2, 20, 32, 2), (3, 33, 16, 2), (1, 12, 128, 2), (1, 129, 32, 1), (2, 8, 64, 3)])
 def test_forward_backward_vs_oracle(ops, B, N, H, L):
     from oracle import ppgn as op
