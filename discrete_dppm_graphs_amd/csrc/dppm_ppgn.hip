@@ -1099,6 +1099,9 @@ __global__ __launch_bounds__(256) void lin32x2w_kernel(const float* __restrict__
 // floats: the A-operand reads of 16 consecutive rows are conflict-free), after_conv / final_lin stay in registers; R and act never
 // leave the wave unless training asks for them (Rs / As, nullable).  logits [B][N][N]; ld = padded row length of the planes.
 constexpr int H32_MAXL = 16;
+// SPLIT (inference, precision bf16x3): layer_cat_lin's blocks and after_conv as three bf16 MFMAs per product on split operands (see
+// mlp32w3_fwd_kernel); the blocks' A fragments are split once per workgroup into LDS behind the float table ([L][2 co][hi, lo][64 lanes] uintx4)
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void head32w_kernel(const float* __restrict__ cat, long cat_bs, const float* __restrict__ Wc, int ldc, const float* __restrict__ bc,
                                                       const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wf, const float* __restrict__ bf,
                                                       float* __restrict__ Rs, float* __restrict__ As, long hs, float* __restrict__ logits, int N, int ld, int L, int B,
@@ -1106,11 +1109,27 @@ __global__ __launch_bounds__(256) void head32w_kernel(const float* __restrict__ 
   extern __shared__ float wlds[];                            // [(2 + 32 L)][33]
   const int P = N * ld, K = 2 + 32 * L;
   for (int i = threadIdx.x; i < 32 * K; i += blockDim.x) { const int o = i / K, k = i - o * K; wlds[k * 33 + o] = Wc[(size_t)o * ldc + k]; }
+  uintx4* frag = reinterpret_cast<uintx4*>(wlds + ((K * 33 + 3) & ~3));
+  if (SPLIT) {
+    for (int i = threadIdx.x; i < L * 2 * 64; i += blockDim.x) {
+      const int ln = i & 63, co = (i >> 6) & 1, l = i >> 7, fq = ln >> 4, fn = ln & 15;
+      const float* row = Wc + (size_t)(16 * co + fn) * ldc + 2 + 32 * l;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = row[(e < 4 ? 4 * fq + e : 16 + 4 * fq + e - 4)];
+      uintx4 h, lo;
+      b32s_split(v, h, lo);
+      frag[((l * 2 + co) * 2 + 0) * 64 + ln] = h;
+      frag[((l * 2 + co) * 2 + 1) * 64 + ln] = lo;
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int gpp = (P + 63) >> 6, ngroups = B * gpp;
   const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
-  const W32 wac = w32_load(Wa, 32, q, n);
+  W32 wac{};
+  W32S wacs{};
+  if (SPLIT) wacs = w32s_load(Wa, 32, q, n); else wac = w32_load(Wa, 32, q, n);
   float wfin[2][4];
 #pragma unroll
   for (int co = 0; co < 2; ++co)
@@ -1140,20 +1159,47 @@ __global__ __launch_bounds__(256) void head32w_kernel(const float* __restrict__ 
     for (int l = 0; l < L; ++l) {
       X32 x = x32_load(cp + (size_t)(2 + 32 * l) * P, P, q, n, at.ok);
       if (aff) { x32_affine(x, t32_load(aff + ((size_t)l * B + at.b) * 64, q)); x32_mask(x, mk); }
-      W32 w;
+      if (SPLIT) {
+        W32S ws;
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
+        for (int co = 0; co < 2; ++co) { ws.h[co] = frag[((l * 2 + co) * 2 + 0) * 64 + lane]; ws.l[co] = frag[((l * 2 + co) * 2 + 1) * 64 + lane]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < 4; ++j) {
+          float v[8];
+          uintx4 h, lo;
 #pragma unroll
-          for (int co = 0; co < 2; ++co) w.w[ci][r][co] = wlds[(2 + 32 * l + 16 * ci + 4 * q + r) * 33 + 16 * co + n];
-      a32_mma(R, w, x);
+          for (int e = 0; e < 8; ++e) v[e] = f4_at(x.v[e >> 2][e & 3], j);
+          b32s_split(v, h, lo);
+          a32s_mma(R, ws, j, h, lo);
+        }
+      } else {
+        W32 w;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int co = 0; co < 2; ++co) w.w[ci][r][co] = wlds[(2 + 32 * l + 16 * ci + 4 * q + r) * 33 + 16 * co + n];
+        a32_mma(R, w, x);
+      }
     }
     a32_bias(R, bc, q);
     if (Rs) a32_store(R, Rs + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
     A32 act;
     a32_zero(act);
-    a32_mma_chain(act, wac, R);
+    if (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8];
+        uintx4 h, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = R.a[j][e >> 2][e & 3];
+        b32s_split(v, h, lo);
+        a32s_mma(act, wacs, j, h, lo);
+      }
+    } else {
+      a32_mma_chain(act, wac, R);
+    }
     a32_bias(act, ba, q);
     a32_leaky(act);
     if (As) a32_store(act, As + (size_t)at.b * hs + at.p0, P, q, n, at.ok);
@@ -1689,16 +1735,18 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   }
   if (fuse32 && !(wide32_ok(P, cat, cat_bs, c.at(w.R), hs) && aligned16(c.at(w.act)))) return fail(DPPM_E_INVALID, "dppm_ppgn_forward: hidden-32 read-out: alignment");
   if (H == 32 && L <= H32_MAXL && wide32_ok(P, cat, cat_bs, c.at(w.R), hs) && aligned16(c.at(w.act))) {   // hidden-32 read-out in one pass
-    const size_t lds = (size_t)(2 + 32 * L) * 33 * sizeof(float);
-    DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&head32w_kernel), lds, "head32w"));
+    const bool hsplit = !training && prec == DPPM_PREC_BF16X3 && sw(SW_DISABLE_MLP32S) == 0;
+    const size_t lds = (size_t)(((2 + 32 * L) * 33 + 3) & ~3) * sizeof(float) + (hsplit ? (size_t)L * 4 * 64 * 16 : 0);
+    auto hkern = hsplit ? head32w_kernel<true> : head32w_kernel<false>;
+    DPPM_TRY(lds_limit(reinterpret_cast<const void*>(hkern), lds, "head32w"));
     const bool prof = prof_enabled();
     if (prof) prof_before(c.st);
     const int grid = wide32_grid(B, P) < 512 ? wide32_grid(B, P) : 512;   // every block stages the weights once
-    hipLaunchKernelGGL(head32w_kernel, dim3(grid), dim3(256), lds, c.st, (const float*)cat, cat_bs, (const float*)pr->cat_w, w.CT, (const float*)pr->cat_b,
+    hipLaunchKernelGGL(hkern, dim3(grid), dim3(256), lds, c.st, (const float*)cat, cat_bs, (const float*)pr->cat_w, w.CT, (const float*)pr->cat_b,
                        (const float*)pr->after_w, (const float*)pr->after_b, (const float*)pr->final_w, (const float*)pr->final_b,
                        training ? c.at(w.R) : (float*)nullptr, training ? c.at(w.act) : (float*)nullptr, hs, logits, N, w.ld, L, B,
                        (const float*)(fuse32 ? naff : nullptr), (const float*)maskp);
-    if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 2.0 * 32 * ((double)w.CT + 32 + 1) * P * B,
+    if (prof) prof_after(c.st, PROF_LINEAR, hsplit ? AR_BF16X3 : AR_F32, 2.0 * 32 * ((double)w.CT + 32 + 1) * P * B,
                          sizeof(float) * ((double)w.CT * P + (training ? 64.0 * P : 0.0) + (double)N * N) * B);
     return check_launch("head32w");
   }
