@@ -1603,7 +1603,7 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   // activations in registers and LDS (dppm_smallgraph.hip).  Inference leaves the workspace untouched; training writes into it
   // exactly what dppm_ppgn_backward reads.
   if (sg_supported(pr, N)) {
-    if (!training) return sg_forward(pr, A, mask, sigma, B, N, logits, nullptr, c.st);
+    if (!training) return sg_forward(pr, A, mask, sigma, B, N, logits, nullptr, c.st, prec == DPPM_PREC_BF16X3 && sw(SW_DISABLE_MLP32S) == 0);
     SgSave sv{c.at(w.maskp), c.at(w.inv_norm), c.at(w.cat), c.at(w.u0), c.at(w.hid1), c.at(w.hid2), c.at(w.o1), c.at(w.o2), c.at(w.mm),
               c.at(w.rstd), c.at(w.R), c.at(w.act), w.S};
     return sg_forward(pr, A, mask, sigma, B, N, logits, &sv, c.st);

@@ -18,6 +18,6 @@ bool sg_supported(const dppm_ppgn_params* pr, int N);
 // logits[B][N][N] of dppm_ppgn_forward (exact float32).  save == nullptr: inference, no workspace is touched; otherwise the
 // activations the backward pass reads are written as well.  Operands as in include/dppm_hip.h.
 int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
-               const SgSave* save, hipStream_t st);
+               const SgSave* save, hipStream_t st, bool split = false);
 
 }  // namespace dppm

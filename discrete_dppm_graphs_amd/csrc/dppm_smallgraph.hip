@@ -109,8 +109,53 @@ __device__ __forceinline__ void sg_commit_b(const float (&pf)[SG_NPF], float* __
   if (tid < 32) W[SG_W_BIAS + 128 + tid] = pf[3 * SG_SPM];
 }
 
+// Split-bf16 form of the 32-wide products (inference, precision bf16x3; SPLIT below): K = 32 is one k step of v_mfma_f32_16x16x32_bf16, and
+// with k slot e of lane group q standing for channel (e < 4 ? 4 q + e : 16 + 4 q + e - 4) the lane's two registers quads [ci][0 .. 3] ARE its B
+// fragment and the two float4 weight reads its A fragment: both are split into bf16 hi / lo pieces where they are used, three MFMAs of
+// 16 cycles per 16 x 16 x 32 block in place of eight of 32 cycles (hi hi + hi lo + lo hi, as in dppm_wsplit.h; the same roundings).
+typedef unsigned int sg_uintx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float sg_floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sg_pack(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(sg_floatx2{a, b}, sg_bf16x2)); }
+__device__ __forceinline__ void sg_split8(const float (&v)[8], sg_uintx4& h, sg_uintx4& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned hh = sg_pack(v[2 * e], v[2 * e + 1]);
+    h[e] = hh;
+    l[e] = sg_pack(v[2 * e] - __uint_as_float(hh << 16), v[2 * e + 1] - __uint_as_float(hh & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ floatx4 sg_mfma3(const sg_uintx4& ah, const sg_uintx4& al, const sg_uintx4& bh, const sg_uintx4& bl, floatx4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, ah), __builtin_bit_cast(sg_bf16x8, bl), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, al), __builtin_bit_cast(sg_bf16x8, bh), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, ah), __builtin_bit_cast(sg_bf16x8, bh), c, 0, 0, 0);
+}
+__device__ __forceinline__ void sg_wfrag(const float* __restrict__ Wm, int wp, int c0, int co, int q, int n, sg_uintx4& h, sg_uintx4& l) {
+  const float4 w0 = *reinterpret_cast<const float4*>(Wm + (16 * co + n) * wp + c0 + 4 * q);
+  const float4 w1 = *reinterpret_cast<const float4*>(Wm + (16 * co + n) * wp + c0 + 16 + 4 * q);
+  const float v[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  sg_split8(v, h, l);
+}
+__device__ __forceinline__ void sg_bfrag(const floatx4 (&src)[2], sg_uintx4& h, sg_uintx4& l) {
+  const float v[8] = {src[0][0], src[0][1], src[0][2], src[0][3], src[1][0], src[1][1], src[1][2], src[1][3]};
+  sg_split8(v, h, l);
+}
+
 // acc[co] (channels 16 co + 4 q + r at the lane's position) += Wm[:, c0 .. c0 + 31] * src, src in the same layout
+template <bool SPLIT>
 __device__ __forceinline__ void sg_mma(floatx4 (&acc)[2], const float* __restrict__ Wm, int wp, int c0, const floatx4 (&src)[2], int q, int n) {
+  if (SPLIT) {
+    sg_uintx4 bh, bl;
+    sg_bfrag(src, bh, bl);
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+      sg_uintx4 ah, al;
+      sg_wfrag(Wm, wp, c0, co, q, n, ah, al);
+      acc[co] = sg_mfma3(ah, al, bh, bl, acc[co]);
+    }
+    return;
+  }
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci) {
     float4 wv[2];
@@ -126,9 +171,23 @@ __device__ __forceinline__ void sg_mma(floatx4 (&acc)[2], const float* __restric
   }
 }
 // the same product for every position tile the wave owns (NTL of them): the weight fragments are read once
-template <int NTL>
+template <int NTL, bool SPLIT>
 __device__ __forceinline__ void sg_mma_all(floatx4 (&acc)[SG_TPW][2], const float* __restrict__ Wm, int wp, int c0,
                                            const floatx4 (&src)[SG_TPW][2], int q, int n) {
+  if (SPLIT) {
+    sg_uintx4 ah[2], al[2];
+#pragma unroll
+    for (int co = 0; co < 2; ++co) sg_wfrag(Wm, wp, c0, co, q, n, ah[co], al[co]);
+#pragma unroll
+    for (int ti = 0; ti < SG_TPW; ++ti) {
+      if (ti >= NTL) continue;
+      sg_uintx4 bh, bl;
+      sg_bfrag(src[ti], bh, bl);
+#pragma unroll
+      for (int co = 0; co < 2; ++co) acc[ti][co] = sg_mfma3(ah[co], al[co], bh, bl, acc[ti][co]);
+    }
+    return;
+  }
   float4 wv[2][2];
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
@@ -202,7 +261,7 @@ __device__ __forceinline__ void sg_block_totals(floatx4 (&s)[2], float* __restri
   }
 }
 
-template <int NTL, bool TWO, bool SAVE>
+template <int NTL, bool TWO, bool SAVE, bool SPLIT>
 __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float* __restrict__ sg_lds) {
   float* O1 = sg_lds;
   float* O2 = O1 + 32 * SG_PITCH;
@@ -287,7 +346,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       floatx4 h[SG_TPW][2], o[SG_TPW][2];
 #pragma unroll
       for (int ti = 0; ti < SG_TPW; ++ti) { h[ti][0] = h[ti][1] = o[ti][0] = o[ti][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-      sg_mma_all<NTL>(h, W + (k ? SG_W_M2A : SG_W_M1A), SG_WP, 0, u, q, n);
+      sg_mma_all<NTL, SPLIT>(h, W + (k ? SG_W_M2A : SG_W_M1A), SG_WP, 0, u, q, n);
 #pragma unroll
       for (int co = 0; co < 2; ++co) {
         const floatx4 bv = sg_bias(W + SG_W_BIAS + (k ? 64 : 0), co, q);
@@ -297,7 +356,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
           for (int r = 0; r < 4; ++r) h[ti][co][r] = sg_leaky(h[ti][co][r] + bv[r]);
       }
       if (SAVE) sg_store_tiles<NTL>((k ? sv.hid2 : sv.hid1) + (size_t)l * sv.S + gS, P, h, so);
-      sg_mma_all<NTL>(o, W + (k ? SG_W_M2B : SG_W_M1B), SG_WP, 0, h, q, n);
+      sg_mma_all<NTL, SPLIT>(o, W + (k ? SG_W_M2B : SG_W_M1B), SG_WP, 0, h, q, n);
       float* Ok = k ? O2 : O1;
 #pragma unroll
       for (int co = 0; co < 2; ++co) {
@@ -401,9 +460,9 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
 #pragma unroll
           for (int r = 0; r < 4; ++r) ms[ti][ci][r] = O1[(16 * ci + 4 * q + r) * SG_PITCH + 16 * SG_TILE(ti) + n];
       }
-      sg_mma_all<NTL>(y, W + SG_W_M4, SG_WP4, 0, ms, q, n);
+      sg_mma_all<NTL, SPLIT>(y, W + SG_W_M4, SG_WP4, 0, ms, q, n);
     }
-    sg_mma_all<NTL>(y, W + SG_W_M4, SG_WP4, 32, u, q, n);
+    sg_mma_all<NTL, SPLIT>(y, W + SG_W_M4, SG_WP4, 32, u, q, n);
 #pragma unroll
     for (int co = 0; co < 2; ++co) {
       const floatx4 bv = sg_bias(W + SG_W_BIAS + 128, co, q);
@@ -449,7 +508,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
         }
     if (SAVE) sg_store_tiles<NTL>(sv.cat + (size_t)b * a.CT * P + (size_t)(2 + 32 * l) * P, P, u, so);
     // ---- this layer's columns of layer_cat_lin (model/ppgn.py:318,327)
-    sg_mma_all<NTL>(yacc, W + SG_W_CAT, SG_WP, 0, u, q, n);
+    sg_mma_all<NTL, SPLIT>(yacc, W + SG_W_CAT, SG_WP, 0, u, q, n);
     SG_T(8);
     SG_T(9);
   }
@@ -461,7 +520,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     if (!SG_HAS(ti)) continue;
     const int pos = 16 * SG_TILE(ti) + n;
     floatx4 act[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
-    sg_mma(act, W + SG_W_M1A, SG_WP, 0, yacc[ti], q, n);
+    sg_mma<SPLIT>(act, W + SG_W_M1A, SG_WP, 0, yacc[ti], q, n);
     float part = 0.f;
 #pragma unroll
     for (int co = 0; co < 2; ++co)
@@ -482,7 +541,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   }
 }
 
-template <bool SAVE>
+template <bool SAVE, bool SPLIT>
 __global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, const SgSave sv) {
   extern __shared__ __attribute__((aligned(16))) float sg_lds[];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -490,11 +549,11 @@ __global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, 
   const int ntl = w < ntile ? (ntile - w + SG_NW - 1) / SG_NW : 0;   // the wave owns tiles w + SG_NW * ti, ti < ntl
   const bool two = a.N > 16;
   switch (ntl) {
-    case 4: if (two) sg_run<4, true, SAVE>(a, sv, sg_lds); else sg_run<4, false, SAVE>(a, sv, sg_lds); break;
-    case 3: if (two) sg_run<3, true, SAVE>(a, sv, sg_lds); else sg_run<3, false, SAVE>(a, sv, sg_lds); break;
-    case 2: if (two) sg_run<2, true, SAVE>(a, sv, sg_lds); else sg_run<2, false, SAVE>(a, sv, sg_lds); break;
-    case 1: if (two) sg_run<1, true, SAVE>(a, sv, sg_lds); else sg_run<1, false, SAVE>(a, sv, sg_lds); break;
-    default: if (two) sg_run<0, true, SAVE>(a, sv, sg_lds); else sg_run<0, false, SAVE>(a, sv, sg_lds); break;
+    case 4: if (two) sg_run<4, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<4, false, SAVE, SPLIT>(a, sv, sg_lds); break;
+    case 3: if (two) sg_run<3, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<3, false, SAVE, SPLIT>(a, sv, sg_lds); break;
+    case 2: if (two) sg_run<2, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<2, false, SAVE, SPLIT>(a, sv, sg_lds); break;
+    case 1: if (two) sg_run<1, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<1, false, SAVE, SPLIT>(a, sv, sg_lds); break;
+    default: if (two) sg_run<0, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<0, false, SAVE, SPLIT>(a, sv, sg_lds); break;
   }
 }
 
@@ -506,7 +565,7 @@ bool sg_supported(const dppm_ppgn_params* pr, int N) {
 }
 
 int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
-               const SgSave* save, hipStream_t st) {
+               const SgSave* save, hipStream_t st, bool split) {   // split: the 32-wide products on the bf16 pipe (inference, precision bf16x3)
   SgArgs a{};
   for (int l = 0; l < pr->num_layers; ++l) a.layer[l] = pr->layers_host[l];
   a.in_w = pr->in_w; a.in_b = pr->in_b; a.cat_w = pr->cat_w; a.cat_b = pr->cat_b;
@@ -515,10 +574,9 @@ int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, co
   a.L = pr->num_layers; a.N = N; a.ld = round_up(N, 4); a.P = N * a.ld; a.CT = 2 + 32 * pr->num_layers;
   const SgSave sv = save ? *save : SgSave{};
   const size_t lds = SG_LDS_FLOATS * sizeof(float);
-  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&sg_forward_kernel<false>), lds, "sg_forward"));
-  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(&sg_forward_kernel<true>), lds, "sg_forward(save)"));
-  if (save) hipLaunchKernelGGL(sg_forward_kernel<true>, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
-  else hipLaunchKernelGGL(sg_forward_kernel<false>, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
+  auto kern = save ? sg_forward_kernel<true, false> : (split ? sg_forward_kernel<false, true> : sg_forward_kernel<false, false>);
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "sg_forward"));
+  hipLaunchKernelGGL(kern, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
   return check_launch("sg_forward");
 }
 

@@ -42,6 +42,45 @@ def test_fused_forward_vs_oracle_and_general_path(ops, B, N, L):
     close(got, _general(ops, W, A, mask, sigma, L, 32), tol=5e-5)
 
 
+@pytest.mark.parametrize("B,N,L", [(2, 5, 3), (3, 16, 6), (32, 18, 6), (32, 20, 6), (2, 20, 16)])
+def test_fused_forward_split_arithmetic(ops, B, N, L):
+    """precision bf16x3 (the samplers' default): the 32-wide products of the one-launch forward run as three bf16 MFMAs on split operands.
+    North-star bar 1e-3 of max |logit| against the oracle (the measured distance is printed); bit-stable; independent of the batch;
+    the golden logits of the reference at ego_small's geometry hold to the same bar."""
+    from oracle import ppgn as op
+    rng = np.random.default_rng(300 * N + L)
+    A, mask = rand_case(rng, B, N, ragged=N >= 6)
+    if N < 6:
+        up = np.triu(rng.random((B, N, N)) < 0.5, 1).astype(np.float32)
+        A = up + up.transpose(0, 2, 1)
+        mask = np.ones((B, N, N), np.float32)
+    sigma = rng.uniform(0, 0.5, size=B)
+    W = op.init_weights(L, 32, seed=N + 1)
+    with torch.no_grad():
+        ref = op.powerful_forward(W, A, mask, sigma, L).squeeze(-1).numpy()
+    got, _ = run_gpu(ops, W, A, mask, sigma, L, 32, precision="bf16x3")
+    exact, _ = run_gpu(ops, W, A, mask, sigma, L, 32)
+    scale = np.abs(ref).max()
+    print(f"\none-launch forward N={N} L={L}: bf16x3 {np.abs(got - ref).max() / scale:.2e}, f32 {np.abs(exact - ref).max() / scale:.2e} of max |logit|")
+    close(got, ref, tol=1e-3)
+    assert not np.array_equal(got, exact)
+    again, _ = run_gpu(ops, W, A, mask, sigma, L, 32, precision="bf16x3")
+    assert np.array_equal(got, again)
+    one, _ = run_gpu(ops, W, A[-1:], mask[-1:], sigma[-1:], L, 32, precision="bf16x3")
+    assert np.array_equal(got[-1:], one)
+    with ops.debug_switch(DISABLE_MLP32S=1):
+        off, _ = run_gpu(ops, W, A, mask, sigma, L, 32, precision="bf16x3")
+    assert np.array_equal(off, exact)
+
+
+def test_fused_forward_golden_reference_logits_split(ops):
+    g = np.load(os.path.join(G, "g1_ppgn_n18_h32_l6.npz"))
+    from discrete_dppm_graphs_amd.ops import used_param_names
+    W = {n: g["w::" + n] for n in used_param_names(6)}
+    lb, _ = run_gpu(ops, W, g["A_t"], g["mask"], float(g["sigmas"][0]), 6, 32, precision="bf16x3")
+    close(lb, g["logits_batched_sigma0"], tol=1e-3)
+
+
 def test_fused_forward_golden_reference_logits(ops):
     """The reference's own logits for ego_small's geometry (N = 18, 6 x 32), one sigma for the whole batch."""
     g = np.load(os.path.join(G, "g1_ppgn_n18_h32_l6.npz"))
