@@ -35,7 +35,8 @@ extern "C" {
 #define DPPM_E_LAUNCH (-2)    /* HIP reported a launch / runtime error */
 #define DPPM_E_UNSUPPORTED (-3)
 
-/* Matrix arithmetic of the H = 128 per-position linears and of the per-channel contraction in INFERENCE forwards (operands and results are float32 in HBM
+/* Matrix arithmetic of the per-position linears (H = 128, and since round 3 H = 32: the wide kernels at N > 20 and the one-launch forward at N <= 20)
+ * and of the per-channel contraction in INFERENCE forwards (operands and results are float32 in HBM
  * in every mode; kernels that have no reduced form use DPPM_PREC_F32 silently; training forward + backward always run
  * float32-grade arithmetic (DPPM_PREC_F32, and DPPM_PREC_F32X6 where a kernel has it): through the backward of the instance
  * norms the 2^-16 products of the two-piece split are amplified to ~50x the float32 gradient error, measured in
@@ -220,8 +221,8 @@ int dppm_linear_fwd(const float* W, int ldw, int trans_w, const float* X, long x
  *   o_k[b] = (W_k1 * LeakyReLU(W_k0 * X[b] + b_k0) + b_k1) * maskp[b],  k = 1, 2      (all matrices H x H, planes H x P).
  * hid1 / hid2 (nullable, both or none): the hidden activations, written only when a backward pass will need them.
  * H = 128 runs the weight-stationary fused kernel (hidden activations stay in LDS); other H use four GEMM launches and
- * then need hid1 / hid2 as scratch (not nullable).  precision != DPPM_PREC_F32 applies to H = 128 without saved hidden
- * activations. */
+ * then need hid1 / hid2 as scratch (not nullable; H = 32 with 16-byte aligned planes runs its own wide kernel).  precision != DPPM_PREC_F32
+ * applies to H = 128 and H = 32 without saved hidden activations. */
 int dppm_mlp_pair_fwd(const float* X, long x_bs, const dppm_ppgn_layer* layer_host, int H, const float* maskp,
                       float* o1, float* o2, float* hid1, float* hid2, int B, int P, int precision, void* stream);
 
