@@ -38,8 +38,11 @@ constexpr int SG_WP4 = 68;          // ... of m4 (64 wide)
 constexpr int SG_W_M1A = 0, SG_W_M1B = 1152, SG_W_M2A = 2304, SG_W_M2B = 3456, SG_W_CAT = 4608, SG_W_M4 = 5760;
 constexpr int SG_W_BIAS = 7936;     // m1_b0, m1_b1, m2_b0, m2_b1, m4_b (32 each)
 constexpr int SG_W_TOTAL = 8096;
+#ifndef SG_SHARE_U
+#define SG_SHARE_U 1                // experiment switch: the split form's two first linears share u's fragment split
+#endif
 constexpr int SG_MP = 416;          // padded mask plane
-constexpr int SG_LDS_FLOATS = 2 * 32 * SG_PITCH + SG_W_TOTAL + SG_MP + 2 * SG_NW * 32 + 64;
+constexpr int SG_LDS_FLOATS = 2 * 32 * SG_PITCH + SG_W_TOTAL + SG_MP + 2 * SG_NW * 32 + 64 + 2 * SG_NW;
 
 // Diagnostic build only (-DSG_STAMP): s_memtime at the phase boundaries of layer 2, wave 0 and wave 1 of workgroup 0
 #ifdef SG_STAMP
@@ -76,12 +79,34 @@ __device__ __forceinline__ void sg_fetch_a(float (&pf)[SG_NPF], const SgArgs& a,
   const int c = tid & 31;   // every thread loads the biases (no branch); threads < 32 commit them
   pf[4 * SG_SPM] = q.m1_b0[c]; pf[4 * SG_SPM + 1] = q.m1_b1[c]; pf[4 * SG_SPM + 2] = q.m2_b0[c]; pf[4 * SG_SPM + 3] = q.m2_b1[c];
 }
+// SPLIT: a matrix element sits in LDS as ONE WORD OF TWO bf16 PIECES (high half: the value rounded to bf16, low half: the rounded
+// remainder), split here once per element instead of once per fragment slot and use (sg_wfrag reads them back with byte permutes)
+typedef unsigned int sg_uintx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float sg_floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sg_pack(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(sg_floatx2{a, b}, sg_bf16x2)); }
+template <bool SPLIT>
+__device__ __forceinline__ void sg_wput2(float* __restrict__ W, int o0, int o1, float v0, float v1) {
+  if constexpr (SPLIT) {
+    const unsigned hh = sg_pack(v0, v1);
+    const unsigned ll = sg_pack(v0 - __uint_as_float(hh << 16), v1 - __uint_as_float(hh & 0xffff0000u));
+    reinterpret_cast<unsigned*>(W)[o0] = __builtin_amdgcn_perm(hh, ll, 0x05040100u);
+    reinterpret_cast<unsigned*>(W)[o1] = __builtin_amdgcn_perm(hh, ll, 0x07060302u);
+  } else {
+    W[o0] = v0; W[o1] = v1;
+  }
+}
+template <bool SPLIT>
 __device__ __forceinline__ void sg_commit_a(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
-#pragma unroll
-  for (int h = 0; h < SG_SPM; ++h) {
-    const int idx = tid + SG_THREADS * h;
-    const int o = (idx >> 5) * SG_WP + (idx & 31);
-    W[SG_W_M1A + o] = pf[h]; W[SG_W_M1B + o] = pf[SG_SPM + h]; W[SG_W_M2A + o] = pf[2 * SG_SPM + h]; W[SG_W_M2B + o] = pf[3 * SG_SPM + h];
+  static_assert(SG_SPM == 2, "two elements of every matrix per thread");
+  {
+    const int i0 = tid, i1 = tid + SG_THREADS;
+    const int o0 = (i0 >> 5) * SG_WP + (i0 & 31), o1 = (i1 >> 5) * SG_WP + (i1 & 31);
+    sg_wput2<SPLIT>(W + SG_W_M1A, o0, o1, pf[0], pf[1]);
+    sg_wput2<SPLIT>(W + SG_W_M1B, o0, o1, pf[SG_SPM], pf[SG_SPM + 1]);
+    sg_wput2<SPLIT>(W + SG_W_M2A, o0, o1, pf[2 * SG_SPM], pf[2 * SG_SPM + 1]);
+    sg_wput2<SPLIT>(W + SG_W_M2B, o0, o1, pf[3 * SG_SPM], pf[3 * SG_SPM + 1]);
   }
   if (tid < 32) {
     W[SG_W_BIAS + tid] = pf[4 * SG_SPM]; W[SG_W_BIAS + 32 + tid] = pf[4 * SG_SPM + 1];
@@ -98,13 +123,14 @@ __device__ __forceinline__ void sg_fetch_b(float (&pf)[SG_NPF], const SgArgs& a,
   }
   pf[3 * SG_SPM] = q.m4_b[tid & 31];
 }
+template <bool SPLIT>
 __device__ __forceinline__ void sg_commit_b(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
-#pragma unroll
-  for (int h = 0; h < SG_SPM; ++h) {
-    const int idx = tid + SG_THREADS * h;
-    W[SG_W_CAT + (idx >> 5) * SG_WP + (idx & 31)] = pf[h];
-    const int o4 = (idx >> 6) * SG_WP4 + (idx & 63);
-    W[SG_W_M4 + o4] = pf[SG_SPM + h]; W[SG_W_M4 + 16 * SG_WP4 + o4] = pf[2 * SG_SPM + h];
+  {
+    const int i0 = tid, i1 = tid + SG_THREADS;
+    sg_wput2<SPLIT>(W + SG_W_CAT, (i0 >> 5) * SG_WP + (i0 & 31), (i1 >> 5) * SG_WP + (i1 & 31), pf[0], pf[1]);
+    const int p0 = (i0 >> 6) * SG_WP4 + (i0 & 63), p1 = (i1 >> 6) * SG_WP4 + (i1 & 63);
+    sg_wput2<SPLIT>(W + SG_W_M4, p0, p1, pf[SG_SPM], pf[SG_SPM + 1]);
+    sg_wput2<SPLIT>(W + SG_W_M4 + 16 * SG_WP4, p0, p1, pf[2 * SG_SPM], pf[2 * SG_SPM + 1]);
   }
   if (tid < 32) W[SG_W_BIAS + 128 + tid] = pf[3 * SG_SPM];
 }
@@ -113,11 +139,6 @@ __device__ __forceinline__ void sg_commit_b(const float (&pf)[SG_NPF], float* __
 // with k slot e of lane group q standing for channel (e < 4 ? 4 q + e : 16 + 4 q + e - 4) the lane's two registers quads [ci][0 .. 3] ARE its B
 // fragment and the two float4 weight reads its A fragment: both are split into bf16 hi / lo pieces where they are used, three MFMAs of
 // 16 cycles per 16 x 16 x 32 block in place of eight of 32 cycles (hi hi + hi lo + lo hi, as in dppm_wsplit.h; the same roundings).
-typedef unsigned int sg_uintx4 __attribute__((ext_vector_type(4)));
-typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float sg_floatx2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned sg_pack(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(sg_floatx2{a, b}, sg_bf16x2)); }
 __device__ __forceinline__ void sg_split8(const float (&v)[8], sg_uintx4& h, sg_uintx4& l) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -132,10 +153,13 @@ __device__ __forceinline__ floatx4 sg_mfma3(const sg_uintx4& ah, const sg_uintx4
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, ah), __builtin_bit_cast(sg_bf16x8, bh), c, 0, 0, 0);
 }
 __device__ __forceinline__ void sg_wfrag(const float* __restrict__ Wm, int wp, int c0, int co, int q, int n, sg_uintx4& h, sg_uintx4& l) {
-  const float4 w0 = *reinterpret_cast<const float4*>(Wm + (16 * co + n) * wp + c0 + 4 * q);
-  const float4 w1 = *reinterpret_cast<const float4*>(Wm + (16 * co + n) * wp + c0 + 16 + 4 * q);
-  const float v[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-  sg_split8(v, h, l);
+  // the words are already (bf16 value, bf16 remainder) pairs: sg_wput2
+  const sg_uintx4 w0 = *reinterpret_cast<const sg_uintx4*>(Wm + (16 * co + n) * wp + c0 + 4 * q);
+  const sg_uintx4 w1 = *reinterpret_cast<const sg_uintx4*>(Wm + (16 * co + n) * wp + c0 + 16 + 4 * q);
+  h[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u); l[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u);
+  h[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u); l[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u);
+  h[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u); l[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
+  h[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u); l[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
 }
 __device__ __forceinline__ void sg_bfrag(const floatx4 (&src)[2], sg_uintx4& h, sg_uintx4& l) {
   const float v[8] = {src[0][0], src[0][1], src[0][2], src[0][3], src[1][0], src[1][1], src[1][2], src[1][3]};
@@ -167,6 +191,25 @@ __device__ __forceinline__ void sg_mma(floatx4 (&acc)[2], const float* __restric
       acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].y, src[ci][1], acc[co], 0, 0, 0);
       acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].z, src[ci][2], acc[co], 0, 0, 0);
       acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[co].w, src[ci][3], acc[co], 0, 0, 0);
+    }
+  }
+}
+// SPLIT only: two matrices against the same source, whose fragment is split once per tile
+template <int NTL>
+__device__ __forceinline__ void sg_mma_all2(floatx4 (&acc1)[SG_TPW][2], floatx4 (&acc2)[SG_TPW][2], const float* __restrict__ W1, const float* __restrict__ W2,
+                                            int wp, int c0, const floatx4 (&src)[SG_TPW][2], int q, int n) {
+  sg_uintx4 a1h[2], a1l[2], a2h[2], a2l[2];
+#pragma unroll
+  for (int co = 0; co < 2; ++co) { sg_wfrag(W1, wp, c0, co, q, n, a1h[co], a1l[co]); sg_wfrag(W2, wp, c0, co, q, n, a2h[co], a2l[co]); }
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    if (ti >= NTL) continue;
+    sg_uintx4 bh, bl;
+    sg_bfrag(src[ti], bh, bl);
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+      acc1[ti][co] = sg_mfma3(a1h[co], a1l[co], bh, bl, acc1[ti][co]);
+      acc2[ti][co] = sg_mfma3(a2h[co], a2l[co], bh, bl, acc2[ti][co]);
     }
   }
 }
@@ -212,7 +255,7 @@ __device__ __forceinline__ floatx4 sg_bias(const float* __restrict__ bv, int co,
   floatx4 r; r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
   return r;
 }
-__device__ __forceinline__ float sg_leaky(float v) { return v > 0.f ? v : kSlopeSg * v; }
+__device__ __forceinline__ float sg_leaky(float v) { return fmaxf(v, kSlopeSg * v); }   // slope < 1: the larger of the two IS the activation
 
 // training: the wave's tiles of a [32][P] plane set of this graph -> HBM (16 lanes = 64 consecutive bytes of one channel).
 // so[ti] = 4 q P + position of the lane in tile ti (or ~0u when outside the plane): uniform pointer + 32-bit lane offset keeps the
@@ -230,23 +273,23 @@ __device__ __forceinline__ void sg_store_tiles(float* __restrict__ base, int P, 
     }
   }
 }
-// sum over the 16 lanes that share q (the positions of a tile), for the lane's 8 channels
-__device__ __forceinline__ void sg_sum16(floatx4 (&s)[2]) {
-#pragma unroll
-  for (int co = 0; co < 2; ++co)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = s[co][r];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      s[co][r] = v;
-    }
+// sum over the 16 lanes that share q (the positions of a tile; one DPP row): every lane ends up with the total
+template <int CTRL> __device__ __forceinline__ float sg_dpp(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float sg_row_sum(float v) {
+  v += sg_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += sg_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += sg_dpp<0x141>(v);   // row_half_mirror
+  v += sg_dpp<0x140>(v);   // row_mirror
+  return v;
 }
-// partial sums of every wave -> totals per channel (all threads)
+
+// partial sums of every wave -> totals per channel (all threads); the training form's two-pass statistics
 __device__ __forceinline__ void sg_block_totals(floatx4 (&s)[2], float* __restrict__ red, int w, int q, int n) {
-  sg_sum16(s);
-  if (n == 0) {
 #pragma unroll
-    for (int co = 0; co < 2; ++co) *reinterpret_cast<float4*>(red + w * 32 + 16 * co + 4 * q) = make_float4(s[co][0], s[co][1], s[co][2], s[co][3]);
+  for (int co = 0; co < 2; ++co) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[co][r] = sg_row_sum(s[co][r]);
+    if (n == 0) *reinterpret_cast<float4*>(red + w * 32 + 16 * co + 4 * q) = make_float4(s[co][0], s[co][1], s[co][2], s[co][3]);
   }
   __syncthreads();
 #pragma unroll
@@ -270,6 +313,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   float* red1 = mp + SG_MP;
   float* red2 = red1 + SG_NW * 32;
   float* dump = red2 + SG_NW * 32;
+  float* cwt = dump + 64;                              // valid positions per wave, and 1 / that (0 for a wave without any)
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane >> 4, n = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile ownership tests become scalar branches
@@ -289,11 +333,12 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cpart += __shfl_xor(cpart, o, 64);
   if (lane == 0) red1[w] = cpart;
-  sg_commit_a(pf, W, tid);
+  sg_commit_a<SPLIT>(pf, W, tid);
   __syncthreads();
   float cnt = 0.f;
 #pragma unroll
   for (int k = 0; k < SG_NW; ++k) cnt += red1[k];
+  const float rcnt = 1.f / cnt;                        // (the one division; the per-layer statistics multiply)
   float s0 = 0.f;
   for (int j = 0; j < ld; ++j) s0 += mp[j];
   const float inv_norm = 1.f / sqrtf(s0);           // model/ppgn.py:51: mask row 0
@@ -325,6 +370,13 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       sv.maskp[(size_t)b * P + pos] = mt[ti];
     }
   }
+  {
+    float cw = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < SG_TPW; ++ti) cw += mt[ti];
+    cw = sg_row_sum(cw);
+    if (lane == 0) { cwt[w] = cw; cwt[SG_NW + w] = cw > 0.f ? 1.f / cw : 0.f; }   // (published by the barriers of the first layer)
+  }
   const size_t gS = (size_t)b * 32 * P;                // this graph inside a [B][32][P] plane set
   unsigned so[SG_TPW];
 #pragma unroll
@@ -336,38 +388,76 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     if (tid == 0) sv.inv_norm[b] = inv_norm;
     sg_store_tiles<NTL>(sv.u0 + gS, P, u, so);
   }
+  int ot[SG_TPW];                                       // SPLIT: the lane's position in a transposed plane (positions past the plane: the pad floats)
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    const int pos = 16 * SG_TILE(ti) + n, pi = pos / ld, pj = pos - pi * ld;
+    ot[ti] = pos < P ? pj * ld + pi : 400 + (lane & 3);
+  }
 
   for (int l = 0; l < L; ++l) {
     sg_fetch_b(pf, a, l, tid);                       // m4 / readout weights of this layer: in flight during the MLP phase
     SG_T(0);
     // ---- m1, m2: Linear -> LeakyReLU -> Linear, * mask (model/ppgn.py:58-59), hidden activations in registers
+    floatx4 hk[2][SG_TPW][2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      floatx4 h[SG_TPW][2], o[SG_TPW][2];
+      floatx4 (&h)[SG_TPW][2] = hk[k];
+      floatx4 o[SG_TPW][2];
 #pragma unroll
-      for (int ti = 0; ti < SG_TPW; ++ti) { h[ti][0] = h[ti][1] = o[ti][0] = o[ti][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-      sg_mma_all<NTL, SPLIT>(h, W + (k ? SG_W_M2A : SG_W_M1A), SG_WP, 0, u, q, n);
+      for (int co = 0; co < 2; ++co) {                 // the biases are the accumulators' initial values
+        const floatx4 bo = sg_bias(W + SG_W_BIAS + (k ? 96 : 32), co, q);
 #pragma unroll
-      for (int co = 0; co < 2; ++co) {
-        const floatx4 bv = sg_bias(W + SG_W_BIAS + (k ? 64 : 0), co, q);
+        for (int ti = 0; ti < SG_TPW; ++ti) o[ti][co] = bo;
+      }
+      constexpr bool SHARE = SPLIT && SG_SHARE_U;
+      if (!SHARE || k == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          if (SHARE ? false : kk != k) continue;
+#pragma unroll
+          for (int co = 0; co < 2; ++co) {
+            const floatx4 bh = sg_bias(W + SG_W_BIAS + (kk ? 64 : 0), co, q);
+#pragma unroll
+            for (int ti = 0; ti < SG_TPW; ++ti) hk[kk][ti][co] = bh;
+          }
+        }
+        // SPLIT: both first linears in one sweep over the tiles -- u's fragment is split once for the two
+        if constexpr (SHARE) sg_mma_all2<NTL>(hk[0], hk[1], W + SG_W_M1A, W + SG_W_M2A, SG_WP, 0, u, q, n);
+        else sg_mma_all<NTL, SPLIT>(h, W + (k ? SG_W_M2A : SG_W_M1A), SG_WP, 0, u, q, n);
+      }
+#pragma unroll
+      for (int co = 0; co < 2; ++co)
 #pragma unroll
         for (int ti = 0; ti < SG_TPW; ++ti)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[ti][co][r] = sg_leaky(h[ti][co][r] + bv[r]);
-      }
+          for (int r = 0; r < 4; ++r) h[ti][co][r] = sg_leaky(h[ti][co][r]);
       if (SAVE) sg_store_tiles<NTL>((k ? sv.hid2 : sv.hid1) + (size_t)l * sv.S + gS, P, h, so);
       sg_mma_all<NTL, SPLIT>(o, W + (k ? SG_W_M2B : SG_W_M1B), SG_WP, 0, h, q, n);
       float* Ok = k ? O2 : O1;
 #pragma unroll
       for (int co = 0; co < 2; ++co) {
-        const floatx4 bv = sg_bias(W + SG_W_BIAS + (k ? 96 : 32), co, q);
 #pragma unroll
         for (int ti = 0; ti < SG_TPW; ++ti) {
           if (ti >= NTL) continue;
+          // SPLIT: o2 is stored TRANSPOSED (plane [j][i], pitch ld), so that the contraction reads both operands as runs of eight k
+          const int pos = (SPLIT && k) ? ot[ti] : 16 * SG_TILE(ti) + n;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            o[ti][co][r] = (o[ti][co][r] + bv[r]) * mt[ti];
-            Ok[(16 * co + 4 * q + r) * SG_PITCH + 16 * SG_TILE(ti) + n] = o[ti][co][r];
+          for (int r = 0; r < 4; ++r) o[ti][co][r] *= mt[ti];
+          if constexpr (SPLIT) {
+            // ... and both operands as WORDS OF TWO bf16 PIECES (high half: the rounded value, low half: the rounded remainder),
+            // split here once per value; the contraction's fragments are then byte permutes of what it reads
+            unsigned* Oku = reinterpret_cast<unsigned*>(Ok) + (16 * co + 4 * q) * SG_PITCH + pos;
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const unsigned hh = sg_pack(o[ti][co][r], o[ti][co][r + 1]);
+              const unsigned ll = sg_pack(o[ti][co][r] - __uint_as_float(hh << 16), o[ti][co][r + 1] - __uint_as_float(hh & 0xffff0000u));
+              Oku[r * SG_PITCH] = __builtin_amdgcn_perm(hh, ll, 0x05040100u);
+              Oku[(r + 1) * SG_PITCH] = __builtin_amdgcn_perm(hh, ll, 0x07060302u);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ok[(16 * co + 4 * q + r) * SG_PITCH + pos] = o[ti][co][r];
           }
         }
       }
@@ -376,7 +466,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     SG_T(1);
     __syncthreads();
     SG_T(2);
-    sg_commit_b(pf, W, tid);                         // every wave is past the previous layer's readout
+    sg_commit_b<SPLIT>(pf, W, tid);                         // every wave is past the previous layer's readout
     sg_fetch_a(pf, a, l + 1, tid);                   // next layer's MLP weights (after_conv after the last layer): in flight from here
 
     // ---- per-channel contraction o1[c] @ o2[c] / sqrt(n) (model/ppgn.py:62-64): SG_CPW channels per wave; result over o1[c]
@@ -384,6 +474,53 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       // k runs over ld = 4 * ksteps <= 20 columns (pad columns hold zeros): all operand reads of the wave's channels are issued
       // up front (fixed trip count 5, steps beyond ld contribute zeros), then the MFMAs run back to back
       constexpr bool two = TWO;                       // N > 16: 2 x 2 output tiles per channel
+      if constexpr (SPLIT) {
+        // K = N <= 20 fits ONE k step of v_mfma_f32_16x16x32_bf16 (lane group q: k = 8 q .. 8 q + 7, dead beyond N).  Issued as
+        // D' = o2^T-rows x o1-rows, so that a lane ends up with mm[i = 16 x + n][j = 16 y + 4 q .. + 3]: both operands are two
+        // 16-byte LDS reads per fragment (o2 was stored transposed for this), the result one 16-byte write per tile -- 8 + 4 LDS
+        // instructions and 12 MFMAs of 16 cycles per channel in place of 20 + 16 and 20 MFMAs of 32 cycles.  The operands arrive
+        // already split (see the MLP phase's store): splitting them here, per fragment slot, cost more VALU time than all of that.
+        const int ia[2] = {min(n, N - 1), min(16 + n, N - 1)}, ja[2] = {min(n, ld - 1), min(16 + n, ld - 1)};
+        const int k0 = q < 3 ? 8 * q : 0;
+        // byte selectors of v_perm_b32 per pair of k (0x0c: a zero byte -- the slots of k >= N, whatever the words there hold)
+        unsigned hs[4], ls[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool l0 = q < 3 && 8 * q + 2 * e < N, l1 = q < 3 && 8 * q + 2 * e + 1 < N;
+          hs[e] = (l0 ? 0x0302u : 0x0c0cu) | (l1 ? 0x07060000u : 0x0c0c0000u);
+          ls[e] = (l0 ? 0x0100u : 0x0c0cu) | (l1 ? 0x05040000u : 0x0c0c0000u);
+        }
+        auto frag = [&](const float* row, sg_uintx4& h, sg_uintx4& lo) {
+          const sg_uintx4 f0 = *reinterpret_cast<const sg_uintx4*>(row + k0), f1 = *reinterpret_cast<const sg_uintx4*>(row + k0 + 4);
+          const unsigned r8[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h[e] = __builtin_amdgcn_perm(r8[2 * e + 1], r8[2 * e], hs[e]);
+            lo[e] = __builtin_amdgcn_perm(r8[2 * e + 1], r8[2 * e], ls[e]);
+          }
+        };
+#pragma unroll 2
+        for (int c = 0; c < SG_CPW; ++c) {
+          float* pa = O1 + (SG_CPW * w + c) * SG_PITCH;
+          const float* pb = O2 + (SG_CPW * w + c) * SG_PITCH;
+          sg_uintx4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (t && !two) continue;
+            frag(pb + ja[t] * ld, ah[t], al[t]);
+            frag(pa + ia[t] * ld, bh[t], bl[t]);
+          }
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+              if ((x || y) && !two) continue;
+              const floatx4 d = sg_mfma3(ah[y], al[y], bh[x], bl[x], floatx4{0.f, 0.f, 0.f, 0.f});
+              const int i = 16 * x + n, j = 16 * y + 4 * q;
+              if (i < N && j < ld) *reinterpret_cast<float4*>(pa + i * ld + j) = make_float4(d[0] * inv_norm, d[1] * inv_norm, d[2] * inv_norm, d[3] * inv_norm);
+            }
+        }
+      } else {
       const int i0 = min(n, N - 1), i1 = min(16 + n, N - 1), j0 = min(n, ld - 1), j1 = min(16 + n, ld - 1);
       // software pipeline over the wave's channels: the operand reads of channel c + 1 are in flight while channel c multiplies
       float a0[5], a1[5], b0[5], b1[5], na0[5], na1[5], nb0[5], nb1[5];
@@ -441,6 +578,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) { a0[ks] = na0[ks]; a1[ks] = na1[ks]; b0[ks] = nb0[ks]; b1[ks] = nb1[ks]; }
       }
+      }
     }
     SG_T(3);
     __syncthreads();
@@ -448,12 +586,12 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
 
     // ---- m4 on cat(mm, x) (model/ppgn.py:66-69), masked instance norm, * mask (util/model_helper.py:176-191, ppgn.py:315)
     floatx4 y[SG_TPW][2];
-    floatx4 s[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
     {
       floatx4 ms[SG_TPW][2];
 #pragma unroll
       for (int ti = 0; ti < SG_TPW; ++ti) {
-        y[ti][0] = y[ti][1] = ms[ti][0] = ms[ti][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+        y[ti][0] = sg_bias(W + SG_W_BIAS + 128, 0, q); y[ti][1] = sg_bias(W + SG_W_BIAS + 128, 1, q);   // bias: the initial value
+        ms[ti][0] = ms[ti][1] = floatx4{0.f, 0.f, 0.f, 0.f};
         if (ti >= NTL) continue;
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
@@ -463,49 +601,107 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       sg_mma_all<NTL, SPLIT>(y, W + SG_W_M4, SG_WP4, 0, ms, q, n);
     }
     sg_mma_all<NTL, SPLIT>(y, W + SG_W_M4, SG_WP4, 32, u, q, n);
-#pragma unroll
-    for (int co = 0; co < 2; ++co) {
-      const floatx4 bv = sg_bias(W + SG_W_BIAS + 128, co, q);
-#pragma unroll
-      for (int ti = 0; ti < SG_TPW; ++ti) {
-        if (ti >= NTL) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          y[ti][co][r] += bv[r];
-          s[co][r] += y[ti][co][r] * mt[ti];
-        }
-      }
-    }
     SG_T(5);
-    sg_block_totals(s, red1, w, q, n);
-    SG_T(6);
-    sg_commit_a(pf, W, tid);                         // the MLP phase of this layer is long over; the next barrier publishes it
     floatx4 mean[2], qs[2];
+    if constexpr (SAVE) {
+      // training form (register budget: the saved tensors' addressing lives beside all this): two passes over the block
+      floatx4 s[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int co = 0; co < 2; ++co)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        mean[co][r] = s[co][r] / cnt;
-        float acc = 0.f;
+      for (int co = 0; co < 2; ++co) {
 #pragma unroll
         for (int ti = 0; ti < SG_TPW; ++ti) {
-          const float d = (y[ti][co][r] - mean[co][r]) * mt[ti];
-          acc += d * d;
-        }
-        qs[co][r] = acc;
-      }
-    sg_block_totals(qs, red2, w, q, n);
-    SG_T(7);
+          if (ti >= NTL) continue;
 #pragma unroll
-    for (int ti = 0; ti < SG_TPW; ++ti)
+          for (int r = 0; r < 4; ++r) s[co][r] += y[ti][co][r] * mt[ti];
+        }
+      }
+      sg_block_totals(s, red1, w, q, n);
+      SG_T(6);
+      sg_commit_a<SPLIT>(pf, W, tid);                       // the MLP phase of this layer is long over; the next barrier publishes it
 #pragma unroll
       for (int co = 0; co < 2; ++co)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float rstd = 1.f / sqrtf(qs[co][r] / cnt + 1e-5f);
-          u[ti][co][r] = (y[ti][co][r] - mean[co][r]) * rstd * mt[ti];
-          if (SAVE && ti == 0 && w == 0 && n == 0) sv.rstd[((size_t)l * gridDim.x + b) * 32 + 16 * co + 4 * q + r] = rstd;
+          mean[co][r] = s[co][r] * rcnt;
+          float acc = 0.f;
+#pragma unroll
+          for (int ti = 0; ti < SG_TPW; ++ti) {
+            const float d = (y[ti][co][r] - mean[co][r]) * mt[ti];
+            acc += d * d;
+          }
+          qs[co][r] = acc;
         }
+      sg_block_totals(qs, red2, w, q, n);
+    } else {
+      // statistics in ONE exchange: every wave's own sum and its sum of squares about ITS OWN mean (both passes stay inside the
+      // wave: registers and DPP row sums), then the pooled variance from the eight (count, mean, M2) -- as stable as two passes over
+      // the block, one barrier less
+      {
+        const float rcw = cwt[SG_NW + w];
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+          floatx4 sw4, qw4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sa = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < SG_TPW; ++ti) {
+              if (ti >= NTL) continue;
+              sa += y[ti][co][r] * mt[ti];
+            }
+            sa = sg_row_sum(sa);
+            const float mw = sa * rcw;
+            float qa = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < SG_TPW; ++ti) {
+              if (ti >= NTL) continue;
+              const float d = (y[ti][co][r] - mw) * mt[ti];
+              qa += d * d;
+            }
+            sw4[r] = sa; qw4[r] = sg_row_sum(qa);
+          }
+          if (n == 0) {
+            *reinterpret_cast<float4*>(red1 + w * 32 + 16 * co + 4 * q) = make_float4(sw4[0], sw4[1], sw4[2], sw4[3]);
+            *reinterpret_cast<float4*>(red2 + w * 32 + 16 * co + 4 * q) = make_float4(qw4[0], qw4[1], qw4[2], qw4[3]);
+          }
+        }
+      }
+      sg_commit_a<SPLIT>(pf, W, tid);                       // the MLP phase of this layer is long over; the barrier below publishes it
+      SG_T(6);
+      __syncthreads();
+#pragma unroll
+      for (int co = 0; co < 2; ++co) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < SG_NW; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(red1 + k * 32 + 16 * co + 4 * q);
+          t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        mean[co][0] = t.x * rcnt; mean[co][1] = t.y * rcnt; mean[co][2] = t.z * rcnt; mean[co][3] = t.w * rcnt;
+        floatx4 m2 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < SG_NW; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(red1 + k * 32 + 16 * co + 4 * q);
+          const float4 g = *reinterpret_cast<const float4*>(red2 + k * 32 + 16 * co + 4 * q);
+          const float ck = cwt[k], rck = cwt[SG_NW + k];
+          const float d0 = v.x * rck - mean[co][0], d1 = v.y * rck - mean[co][1], d2 = v.z * rck - mean[co][2], d3 = v.w * rck - mean[co][3];
+          m2[0] += g.x + ck * d0 * d0; m2[1] += g.y + ck * d1 * d1; m2[2] += g.z + ck * d2 * d2; m2[3] += g.w + ck * d3 * d3;
+        }
+        qs[co] = m2;
+      }
+    }
+    SG_T(7);
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // v_rsq_f32 (1 ulp) in inference; the training form keeps the correctly rounded pair, its rstd is saved for the backward
+        const float var = qs[co][r] * rcnt + 1e-5f;
+        const float rstd = SAVE ? 1.f / sqrtf(var) : __builtin_amdgcn_rsqf(var);
+#pragma unroll
+        for (int ti = 0; ti < SG_TPW; ++ti) u[ti][co][r] = (y[ti][co][r] - mean[co][r]) * rstd * mt[ti];
+        if (SAVE && w == 0 && n == 0) sv.rstd[((size_t)l * gridDim.x + b) * 32 + 16 * co + 4 * q + r] = rstd;
+      }
     if (SAVE) sg_store_tiles<NTL>(sv.cat + (size_t)b * a.CT * P + (size_t)(2 + 32 * l) * P, P, u, so);
     // ---- this layer's columns of layer_cat_lin (model/ppgn.py:318,327)
     sg_mma_all<NTL, SPLIT>(yacc, W + SG_W_CAT, SG_WP, 0, u, q, n);
