@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdppm_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # DPPM_PREC_* of include/dppm_hip.h
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2, "f32x6": 3}
@@ -58,6 +58,9 @@ SIGNATURES = {
                                     C.c_size_t, C.c_int, C.c_int, c_stream]),
     "dppm_ppgn_backward": (C.c_int, [C.POINTER(PpgnParams), C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                      c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "dppm_ppgn_chain_simple_supported": (C.c_int, [C.POINTER(PpgnParams), C.c_int]),
+    "dppm_ppgn_chain_simple": (C.c_int, [C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                         c_f32p, C.c_int, c_stream]),
     "dppm_plane_matmul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
                                     C.c_int, C.c_int, c_stream]),
     "dppm_linear_fwd": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_long, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_long,

@@ -57,7 +57,7 @@ int lds_limit(const void* kernel, size_t bytes, const char* what);
 // into one table; afterwards only dppm_debug_set (include/dppm_hip_debug.h) changes them.  No kernel choice depends on anything else.
 enum Switch { SW_DISABLE_WSTAT, SW_DISABLE_W6, SW_DISABLE_W6MLP, SW_DISABLE_LIN32, SW_DISABLE_W4, SW_W3MLP, SW_DISABLE_MLP32, SW_DISABLE_WGRAD32,
               SW_WGRAD_F32, SW_DISABLE_STRIPMM, SW_DISABLE_PLANE4, SW_DISABLE_PLANE6, SW_DISABLE_NORMFUSE, SW_DISABLE_HEAD3,
-              SW_DISABLE_INLINFUSE, SW_DISABLE_SMALLGRAPH, SW_PLANE_STRIPS_ONLY, SW_DISABLE_WIDE32, SW_DISABLE_MLP32S, SW_DBG, SW_DBG_P4, SW_DBG_W4, SW_COUNT };
+              SW_DISABLE_INLINFUSE, SW_DISABLE_SMALLGRAPH, SW_PLANE_STRIPS_ONLY, SW_DISABLE_WIDE32, SW_DISABLE_MLP32S, SW_DISABLE_SGCHAIN, SW_DBG, SW_DBG_P4, SW_DBG_W4, SW_COUNT };
 int sw(Switch s);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

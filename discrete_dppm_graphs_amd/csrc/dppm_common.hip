@@ -44,7 +44,7 @@ namespace dppm {
 namespace {
 const char* const kSwitchNames[SW_COUNT] = {"DISABLE_WSTAT", "DISABLE_W6", "DISABLE_W6MLP", "DISABLE_LIN32", "DISABLE_W4", "W3MLP", "DISABLE_MLP32",
                                             "DISABLE_WGRAD32", "WGRAD_F32", "DISABLE_STRIPMM", "DISABLE_PLANE4", "DISABLE_PLANE6", "DISABLE_NORMFUSE",
-                                            "DISABLE_HEAD3", "DISABLE_INLINFUSE", "DISABLE_SMALLGRAPH", "PLANE_STRIPS_ONLY", "DISABLE_WIDE32", "DISABLE_MLP32S", "DBG", "DBG_P4", "DBG_W4"};
+                                            "DISABLE_HEAD3", "DISABLE_INLINFUSE", "DISABLE_SMALLGRAPH", "PLANE_STRIPS_ONLY", "DISABLE_WIDE32", "DISABLE_MLP32S", "DISABLE_SGCHAIN", "DBG", "DBG_P4", "DBG_W4"};
 struct Switches {
   std::atomic<int> v[SW_COUNT];
   Switches() {
@@ -131,4 +131,4 @@ extern "C" int dppm_prof_end(double* ms, double* work, double* bytes, long* laun
 }
 
 extern "C" const char* dppm_last_error(void) { return dppm::error_buffer(); }
-extern "C" int dppm_abi_version(void) { return 4; }
+extern "C" int dppm_abi_version(void) { return 5; }

@@ -18,6 +18,7 @@
 //   * the layer's weights (32 KB) sit in LDS; the next layer's are fetched into 8 registers per thread while this one runs.
 // One workgroup per graph; LDS 141.6 KB of the 160 KB a CU has.
 #include "dppm_smallgraph.h"
+#include "dppm_philox.h"
 #include <cstdlib>
 
 namespace dppm {
@@ -42,7 +43,7 @@ constexpr int SG_W_TOTAL = 8096;
 #define SG_SHARE_U 1                // experiment switch: the split form's two first linears share u's fragment split
 #endif
 constexpr int SG_MP = 416;          // padded mask plane
-constexpr int SG_LDS_FLOATS = 2 * 32 * SG_PITCH + SG_W_TOTAL + SG_MP + 2 * SG_NW * 32 + 64 + 2 * SG_NW;
+constexpr int SG_LDS_FLOATS = 2 * 32 * SG_PITCH + SG_W_TOTAL + SG_MP + 2 * SG_NW * 32 + 64 + 2 * SG_NW + 2 * SG_MP;
 
 // Diagnostic build only (-DSG_STAMP): s_memtime at the phase boundaries of layer 2, wave 0 and wave 1 of workgroup 0
 #ifdef SG_STAMP
@@ -52,7 +53,19 @@ __device__ unsigned long long sg_stamps[64];
 #define SG_T(i) do {} while (0)
 #endif
 
+// The simple sampling chain inside the kernel (CHAIN; sample_ppgn_simple.py:70-88): per level c the re-noising of x0_hat
+// (FlipOp of dppm_diffusion.hip, draw offset 1 + 2 c), the forward, the reverse step (RevSimpleOp, offset 2 + 2 c); x_T is InitOp's
+// (offset 0).  Thread tid < P owns entry (tid / ld, tid % ld) of the upper triangle and its mirror: the same Philox counters, the
+// same float expressions, hence the same bits as the per-level launches.
+struct SgChain {
+  int T;                 // noise levels
+  const float* tab;      // [T][3] on the device: the network's noise input float(sigma), float(1 - sigma), float(sigma) (rounded from double)
+  const float* flags;    // [B][N]
+  uint64_t seed; uint32_t graph_id0;
+  float* x;              // [B][N][N]: the sampled adjacency
+};
 struct SgArgs {
+  SgChain ch;
   dppm_ppgn_layer layer[SG_MAX_LAYERS];
   const float *in_w, *in_b, *cat_w, *cat_b, *after_w, *after_b, *final_w, *final_b;
   const float *A, *mask, *sigma;
@@ -67,17 +80,27 @@ struct SgArgs {
 //   group B = m4, the layer's columns of layer_cat_lin and m4's bias, fetched at the top of layer l and committed after the MLP
 //             phase's barrier (every wave is then past the readout of layer l - 1), read after the contraction's barrier.
 // No barrier exists for the weights alone.
-__device__ __forceinline__ void sg_fetch_a(float (&pf)[SG_NPF], const SgArgs& a, int l, int tid) {
-  const int lc = l < a.L ? l : a.L - 1;
-  const dppm_ppgn_layer& q = a.layer[lc];
-  const float* p0 = l < a.L ? q.m1_w0 : a.after_w;
+// The tensor pointers of a layer sit in the kernel arguments under a run-time index: they are read (scalar loads) at the TOP of the
+// layer that will use them, all together, so that neither fetch below waits for them in the middle of a phase.
+struct SgPtrA { const float *w[4], *b[4]; };
+struct SgPtrB { const float *cat, *m4w, *m4b; };
+typedef const __attribute__((address_space(4))) SgArgs* SgKernarg;   // the argument block where it lies (constant address space: scalar loads)
+__device__ __forceinline__ SgPtrA sg_ptr_a(SgKernarg a, int l) {
+  const int lc = l < a->L ? l : a->L - 1;
+  return SgPtrA{{l < a->L ? a->layer[lc].m1_w0 : a->after_w, a->layer[lc].m1_w1, a->layer[lc].m2_w0, a->layer[lc].m2_w1},
+                {a->layer[lc].m1_b0, a->layer[lc].m1_b1, a->layer[lc].m2_b0, a->layer[lc].m2_b1}};
+}
+__device__ __forceinline__ SgPtrB sg_ptr_b(SgKernarg a, int l) {
+  return SgPtrB{a->cat_w + 2 + 32 * l, a->layer[l].m4_w, a->layer[l].m4_b};
+}
+__device__ __forceinline__ void sg_fetch_a(float (&pf)[SG_NPF], const SgPtrA& p, int tid) {
 #pragma unroll
   for (int h = 0; h < SG_SPM; ++h) {
     const int idx = tid + SG_THREADS * h;
-    pf[h] = p0[idx]; pf[SG_SPM + h] = q.m1_w1[idx]; pf[2 * SG_SPM + h] = q.m2_w0[idx]; pf[3 * SG_SPM + h] = q.m2_w1[idx];
+    pf[h] = p.w[0][idx]; pf[SG_SPM + h] = p.w[1][idx]; pf[2 * SG_SPM + h] = p.w[2][idx]; pf[3 * SG_SPM + h] = p.w[3][idx];
   }
   const int c = tid & 31;   // every thread loads the biases (no branch); threads < 32 commit them
-  pf[4 * SG_SPM] = q.m1_b0[c]; pf[4 * SG_SPM + 1] = q.m1_b1[c]; pf[4 * SG_SPM + 2] = q.m2_b0[c]; pf[4 * SG_SPM + 3] = q.m2_b1[c];
+  pf[4 * SG_SPM] = p.b[0][c]; pf[4 * SG_SPM + 1] = p.b[1][c]; pf[4 * SG_SPM + 2] = p.b[2][c]; pf[4 * SG_SPM + 3] = p.b[3][c];
 }
 // SPLIT: a matrix element sits in LDS as ONE WORD OF TWO bf16 PIECES (high half: the value rounded to bf16, low half: the rounded
 // remainder), split here once per element instead of once per fragment slot and use (sg_wfrag reads them back with byte permutes)
@@ -113,15 +136,14 @@ __device__ __forceinline__ void sg_commit_a(const float (&pf)[SG_NPF], float* __
     W[SG_W_BIAS + 64 + tid] = pf[4 * SG_SPM + 2]; W[SG_W_BIAS + 96 + tid] = pf[4 * SG_SPM + 3];
   }
 }
-__device__ __forceinline__ void sg_fetch_b(float (&pf)[SG_NPF], const SgArgs& a, int l, int tid) {
-  const dppm_ppgn_layer& q = a.layer[l];
+__device__ __forceinline__ void sg_fetch_b(float (&pf)[SG_NPF], const SgPtrB& p, int CT, int tid) {
 #pragma unroll
   for (int h = 0; h < SG_SPM; ++h) {
     const int idx = tid + SG_THREADS * h;
-    pf[h] = a.cat_w[(size_t)(idx >> 5) * a.CT + 2 + 32 * l + (idx & 31)];
-    pf[SG_SPM + h] = q.m4_w[idx]; pf[2 * SG_SPM + h] = q.m4_w[1024 + idx];
+    pf[h] = p.cat[(size_t)(idx >> 5) * CT + (idx & 31)];
+    pf[SG_SPM + h] = p.m4w[idx]; pf[2 * SG_SPM + h] = p.m4w[1024 + idx];
   }
-  pf[3 * SG_SPM] = q.m4_b[tid & 31];
+  pf[3 * SG_SPM] = p.m4b[tid & 31];
 }
 template <bool SPLIT>
 __device__ __forceinline__ void sg_commit_b(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
@@ -304,7 +326,9 @@ __device__ __forceinline__ void sg_block_totals(floatx4 (&s)[2], float* __restri
   }
 }
 
-template <int NTL, bool TWO, bool SAVE, bool SPLIT>
+__device__ __forceinline__ float sg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }   // sigmoidf_dev of dppm_diffusion.hip
+
+template <int NTL, bool TWO, bool SAVE, bool SPLIT, bool CHAIN>
 __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float* __restrict__ sg_lds) {
   float* O1 = sg_lds;
   float* O2 = O1 + 32 * SG_PITCH;
@@ -314,16 +338,21 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   float* red2 = red1 + SG_NW * 32;
   float* dump = red2 + SG_NW * 32;
   float* cwt = dump + 64;                              // valid positions per wave, and 1 / that (0 for a wave without any)
+  float* at = cwt + 2 * SG_NW;                         // CHAIN: the noisy adjacency of the level, padded plane [N][ld]
+  float* lg = at + SG_MP;                              // CHAIN: the logits of the level
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane >> 4, n = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile ownership tests become scalar branches
   const int N = a.N, ld = a.ld, P = a.P, L = a.L;
+  // The layer table is indexed at run time: read it where it lies, in the kernel-argument segment (SgArgs is the kernel's first
+  // parameter, offset 0).  Through the by-value copy `a` a run-time index can make the compiler move the whole block to scratch.
+  const SgKernarg ka = (SgKernarg)__builtin_amdgcn_kernarg_segment_ptr();
   // the wave owns position tiles w + SG_NW * ti, ti < SG_TPW, as far as they exist (ntile <= 25)
 #define SG_TILE(ti) (w + SG_NW * (ti))
 #define SG_HAS(ti) ((ti) < NTL)
 
   float pf[SG_NPF];
-  sg_fetch_a(pf, a, 0, tid);
+  sg_fetch_a(pf, sg_ptr_a(ka, 0), tid);
   if (tid < SG_MP) {
     const int i = tid / ld, j = tid - i * ld;
     mp[tid] = (tid < P && j < N) ? a.mask[((size_t)b * N + i) * N + j] : 0.f;
@@ -343,33 +372,10 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   for (int j = 0; j < ld; ++j) s0 += mp[j];
   const float inv_norm = 1.f / sqrtf(s0);           // model/ppgn.py:51: mask row 0
 
-  // input planes [A, sigma I], in_lin (model/ppgn.py:283-301) and the [A, sigma I] columns of layer_cat_lin (:318,327)
-  floatx4 u[SG_TPW][2], yacc[SG_TPW][2];
   float mt[SG_TPW];
-  const float sg = a.sigma[b];
 #pragma unroll
-  for (int ti = 0; ti < SG_TPW; ++ti) {
-    const int pos = 16 * SG_TILE(ti) + n;
-    const bool tv = SG_HAS(ti);
-    const int i = pos / ld, j = pos - i * ld;
-    const bool in = tv && pos < P && j < N;
-    const float av = in ? a.A[((size_t)b * N + i) * N + j] : 0.f;
-    const float sgv = (in && i == j) ? sg : 0.f;
-    mt[ti] = tv ? mp[pos] : 0.f;
-#pragma unroll
-    for (int co = 0; co < 2; ++co)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ch = 16 * co + 4 * q + r;
-        u[ti][co][r] = a.in_w[2 * ch] * av + a.in_w[2 * ch + 1] * sgv + a.in_b[ch];
-        yacc[ti][co][r] = a.cat_w[(size_t)ch * a.CT] * av + a.cat_w[(size_t)ch * a.CT + 1] * sgv + a.cat_b[ch];
-      }
-    if (SAVE && tv && pos < P && q == 0) {             // the input planes of CAT and the padded mask
-      sv.cat[(size_t)b * a.CT * P + pos] = av;
-      sv.cat[(size_t)b * a.CT * P + P + pos] = sgv;
-      sv.maskp[(size_t)b * P + pos] = mt[ti];
-    }
-  }
+  for (int ti = 0; ti < SG_TPW; ++ti) mt[ti] = SG_HAS(ti) ? mp[16 * SG_TILE(ti) + n] : 0.f;
+
   {
     float cw = 0.f;
 #pragma unroll
@@ -384,10 +390,9 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     const int pos = 16 * SG_TILE(ti) + n;
     so[ti] = (SG_HAS(ti) && pos < P) ? (unsigned)(4 * q * P + pos) : ~0u;
   }
-  if (SAVE) {
-    if (tid == 0) sv.inv_norm[b] = inv_norm;
-    sg_store_tiles<NTL>(sv.u0 + gS, P, u, so);
-  }
+  float mtn[SG_TPW];
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) mtn[ti] = mt[ti] * inv_norm;
   int ot[SG_TPW];                                       // SPLIT: the lane's position in a transposed plane (positions past the plane: the pad floats)
 #pragma unroll
   for (int ti = 0; ti < SG_TPW; ++ti) {
@@ -395,8 +400,67 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     ot[ti] = pos < P ? pj * ld + pi : 400 + (lane & 3);
   }
 
+  // CHAIN: x_T and the first re-noising
+  const int ci = tid / ld, cj = tid - ci * ld;
+  const bool cup = CHAIN && tid < P && ci < cj && cj < N;
+  const uint32_t cg = CHAIN ? a.ch.graph_id0 + (uint32_t)b : 0u;
+  float cfi = 0.f, cfj = 0.f, cx = 0.f;
+  const float* ctab = a.ch.tab;                        // (locals: a lambda that names `a` would move the whole argument block to scratch)
+  const uint64_t cseed = a.ch.seed;
+  const uint32_t cgid = cg;
+  auto renoise = [=, &cx, &cfi, &cfj](int c) {   // (by value: nothing here may name `a`)   // FlipOp: keep an edge state with 1 - sigma, flip it with sigma
+    const float pr = cx > 0.5f ? ctab[3 * c + 1] : ctab[3 * c + 2];
+    const float v = philox_uniform(cseed, cgid, 1u + 2u * (uint32_t)c, (uint32_t)ci, (uint32_t)cj) < pr ? 1.f : 0.f;
+    at[ci * ld + cj] = at[cj * ld + ci] = v * cfi * cfj;
+  };
+  if (CHAIN) {
+    if (tid < SG_MP) at[tid] = 0.f;                    // diagonal and pad columns stay zero
+    __syncthreads();
+    if (cup) {
+      cfi = a.ch.flags[b * N + ci]; cfj = a.ch.flags[b * N + cj];
+      const float pr = (cfi > 0.5f && cfj > 0.5f) ? 0.5f : 0.f;   // InitOp
+      cx = philox_uniform(cseed, cg, 0u, (uint32_t)ci, (uint32_t)cj) < pr ? 1.f : 0.f;
+      renoise(0);
+    }
+    __syncthreads();
+  }
+
+  const int nlev = CHAIN ? a.ch.T : 1;
+  for (int c = 0; c < nlev; ++c) {
+  // input planes [A, sigma I], in_lin (model/ppgn.py:283-301) and the [A, sigma I] columns of layer_cat_lin (:318,327)
+  floatx4 u[SG_TPW][2], yacc[SG_TPW][2];
+  const float sg = CHAIN ? ctab[3 * c] : a.sigma[b];
+#pragma unroll
+  for (int ti = 0; ti < SG_TPW; ++ti) {
+    const int pos = 16 * SG_TILE(ti) + n;
+    const bool tv = SG_HAS(ti);
+    const int i = pos / ld, j = pos - i * ld;
+    const bool in = tv && pos < P && j < N;
+    const float av = in ? (CHAIN ? at[pos] : a.A[((size_t)b * N + i) * N + j]) : 0.f;
+    const float sgv = (in && i == j) ? sg : 0.f;
+#pragma unroll
+    for (int co = 0; co < 2; ++co)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * co + 4 * q + r;
+        u[ti][co][r] = a.in_w[2 * ch] * av + a.in_w[2 * ch + 1] * sgv + a.in_b[ch];
+        yacc[ti][co][r] = a.cat_w[(size_t)ch * a.CT] * av + a.cat_w[(size_t)ch * a.CT + 1] * sgv + a.cat_b[ch];
+      }
+    if (SAVE && tv && pos < P && q == 0) {             // the input planes of CAT and the padded mask
+      sv.cat[(size_t)b * a.CT * P + pos] = av;
+      sv.cat[(size_t)b * a.CT * P + P + pos] = sgv;
+      sv.maskp[(size_t)b * P + pos] = mt[ti];
+    }
+  }
+  if (SAVE) {
+    if (tid == 0) sv.inv_norm[b] = inv_norm;
+    sg_store_tiles<NTL>(sv.u0 + gS, P, u, so);
+  }
+
   for (int l = 0; l < L; ++l) {
-    sg_fetch_b(pf, a, l, tid);                       // m4 / readout weights of this layer: in flight during the MLP phase
+    const SgPtrB pB = sg_ptr_b(ka, l);
+    const SgPtrA pA = sg_ptr_a(ka, l + 1);
+    sg_fetch_b(pf, pB, a.CT, tid);                       // m4 / readout weights of this layer: in flight during the MLP phase
     SG_T(0);
     // ---- m1, m2: Linear -> LeakyReLU -> Linear, * mask (model/ppgn.py:58-59), hidden activations in registers
     floatx4 hk[2][SG_TPW][2];
@@ -443,7 +507,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
           // SPLIT: o2 is stored TRANSPOSED (plane [j][i], pitch ld), so that the contraction reads both operands as runs of eight k
           const int pos = (SPLIT && k) ? ot[ti] : 16 * SG_TILE(ti) + n;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[ti][co][r] *= mt[ti];
+          for (int r = 0; r < 4; ++r) o[ti][co][r] *= (SPLIT && k == 0) ? mtn[ti] : mt[ti];   // SPLIT: 1 / sqrt(n) of the contraction rides on o1
           if constexpr (SPLIT) {
             // ... and both operands as WORDS OF TWO bf16 PIECES (high half: the rounded value, low half: the rounded remainder),
             // split here once per value; the contraction's fragments are then byte permutes of what it reads
@@ -465,9 +529,9 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     }
     SG_T(1);
     __syncthreads();
-    SG_T(2);
     sg_commit_b<SPLIT>(pf, W, tid);                         // every wave is past the previous layer's readout
-    sg_fetch_a(pf, a, l + 1, tid);                   // next layer's MLP weights (after_conv after the last layer): in flight from here
+    sg_fetch_a(pf, pA, tid);                   // next layer's MLP weights (after_conv after the last layer): in flight from here
+    SG_T(2);
 
     // ---- per-channel contraction o1[c] @ o2[c] / sqrt(n) (model/ppgn.py:62-64): SG_CPW channels per wave; result over o1[c]
     {
@@ -499,7 +563,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
             lo[e] = __builtin_amdgcn_perm(r8[2 * e + 1], r8[2 * e], ls[e]);
           }
         };
-#pragma unroll 2
+#pragma unroll
         for (int c = 0; c < SG_CPW; ++c) {
           float* pa = O1 + (SG_CPW * w + c) * SG_PITCH;
           const float* pb = O2 + (SG_CPW * w + c) * SG_PITCH;
@@ -517,7 +581,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
               if ((x || y) && !two) continue;
               const floatx4 d = sg_mfma3(ah[y], al[y], bh[x], bl[x], floatx4{0.f, 0.f, 0.f, 0.f});
               const int i = 16 * x + n, j = 16 * y + 4 * q;
-              if (i < N && j < ld) *reinterpret_cast<float4*>(pa + i * ld + j) = make_float4(d[0] * inv_norm, d[1] * inv_norm, d[2] * inv_norm, d[3] * inv_norm);
+              if (i < N && j < ld) *reinterpret_cast<float4*>(pa + i * ld + j) = make_float4(d[0], d[1], d[2], d[3]);   // (1 / sqrt(n): in o1 already)
             }
         }
       } else {
@@ -667,6 +731,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
         }
       }
       sg_commit_a<SPLIT>(pf, W, tid);                       // the MLP phase of this layer is long over; the barrier below publishes it
+      if (CHAIN && l == L - 1) sg_fetch_a(pf, sg_ptr_a(ka, 0), tid);   // next level's first layer: in flight through read-out and head
       SG_T(6);
       __syncthreads();
 #pragma unroll
@@ -733,11 +798,31 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
     const int i = pos / ld, j = pos - i * ld;
-    if (q == 0 && pos < P && j < N) a.logits[((size_t)b * N + i) * N + j] = part + fb;
+    if (q == 0 && pos < P && j < N) (CHAIN ? lg + pos : a.logits + ((size_t)b * N + i) * N + j)[0] = part + fb;
+  }
+  if (CHAIN) {
+    __syncthreads();                                   // the logits are complete and every wave is done with after_conv's weights
+    sg_commit_a<SPLIT>(pf, W, tid);                    // layer 0's MLP weights for the next level (fetched behind the last commit above)
+    if (cup) {
+      // RevSimpleOp: flip where the symmetrised probability says so, then (FlipOp) re-noise for the next level
+      float r = (sg_sigmoid(lg[ci * ld + cj]) + sg_sigmoid(lg[cj * ld + ci])) / 2.f;
+      r = r * ((cfi >= 0.9f && cfj >= 0.9f) ? 1.f : 0.f);
+      const float v = philox_uniform(cseed, cg, 2u + 2u * (uint32_t)c, (uint32_t)ci, (uint32_t)cj) < r ? 1.f : 0.f;
+      const float av = at[ci * ld + cj];
+      const float inter = v > 0.5f ? av - 1.f : av;
+      cx = inter < -0.5f ? inter + 2.f : inter;
+      if (c + 1 < nlev) renoise(c + 1);
+    }
+    __syncthreads();
+  }
+  }   // levels
+  if (CHAIN && tid < P && cj < N) {
+    if (ci < cj) a.ch.x[((size_t)b * N + ci) * N + cj] = a.ch.x[((size_t)b * N + cj) * N + ci] = cx;
+    else if (ci == cj) a.ch.x[((size_t)b * N + ci) * N + cj] = 0.f;
   }
 }
 
-template <bool SAVE, bool SPLIT>
+template <bool SAVE, bool SPLIT, bool CHAIN>
 __global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, const SgSave sv) {
   extern __shared__ __attribute__((aligned(16))) float sg_lds[];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -745,11 +830,11 @@ __global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, 
   const int ntl = w < ntile ? (ntile - w + SG_NW - 1) / SG_NW : 0;   // the wave owns tiles w + SG_NW * ti, ti < ntl
   const bool two = a.N > 16;
   switch (ntl) {
-    case 4: if (two) sg_run<4, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<4, false, SAVE, SPLIT>(a, sv, sg_lds); break;
-    case 3: if (two) sg_run<3, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<3, false, SAVE, SPLIT>(a, sv, sg_lds); break;
-    case 2: if (two) sg_run<2, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<2, false, SAVE, SPLIT>(a, sv, sg_lds); break;
-    case 1: if (two) sg_run<1, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<1, false, SAVE, SPLIT>(a, sv, sg_lds); break;
-    default: if (two) sg_run<0, true, SAVE, SPLIT>(a, sv, sg_lds); else sg_run<0, false, SAVE, SPLIT>(a, sv, sg_lds); break;
+    case 4: if (two) sg_run<4, true, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); else sg_run<4, false, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); break;
+    case 3: if (two) sg_run<3, true, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); else sg_run<3, false, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); break;
+    case 2: if (two) sg_run<2, true, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); else sg_run<2, false, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); break;
+    case 1: if (two) sg_run<1, true, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); else sg_run<1, false, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); break;
+    default: if (two) sg_run<0, true, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); else sg_run<0, false, SAVE, SPLIT, CHAIN>(a, sv, sg_lds); break;
   }
 }
 
@@ -760,20 +845,37 @@ bool sg_supported(const dppm_ppgn_params* pr, int N) {
   return !off && pr->hidden == 32 && N >= 1 && N <= SG_MAX_NODES && pr->num_layers <= SG_MAX_LAYERS && !pr->layer_cond;
 }
 
-int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
-               const SgSave* save, hipStream_t st, bool split) {   // split: the 32-wide products on the bf16 pipe (inference, precision bf16x3)
-  SgArgs a{};
+static void sg_fill_args(SgArgs& a, const dppm_ppgn_params* pr, int N) {
   for (int l = 0; l < pr->num_layers; ++l) a.layer[l] = pr->layers_host[l];
   a.in_w = pr->in_w; a.in_b = pr->in_b; a.cat_w = pr->cat_w; a.cat_b = pr->cat_b;
   a.after_w = pr->after_w; a.after_b = pr->after_b; a.final_w = pr->final_w; a.final_b = pr->final_b;
-  a.A = A; a.mask = mask; a.sigma = sigma; a.logits = logits;
   a.L = pr->num_layers; a.N = N; a.ld = round_up(N, 4); a.P = N * a.ld; a.CT = 2 + 32 * pr->num_layers;
+}
+
+int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
+               const SgSave* save, hipStream_t st, bool split) {   // split: the 32-wide products on the bf16 pipe (inference, precision bf16x3)
+  SgArgs a{};
+  sg_fill_args(a, pr, N);
+  a.A = A; a.mask = mask; a.sigma = sigma; a.logits = logits;
   const SgSave sv = save ? *save : SgSave{};
   const size_t lds = SG_LDS_FLOATS * sizeof(float);
-  auto kern = save ? sg_forward_kernel<true, false> : (split ? sg_forward_kernel<false, true> : sg_forward_kernel<false, false>);
+  auto kern = save ? sg_forward_kernel<true, false, false> : (split ? sg_forward_kernel<false, true, false> : sg_forward_kernel<false, false, false>);
   DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "sg_forward"));
   hipLaunchKernelGGL(kern, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
   return check_launch("sg_forward");
+}
+
+int sg_chain_simple(const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_tab, int T, uint64_t seed,
+                    uint32_t graph_id0, int B, int N, float* x, hipStream_t st, bool split) {
+  SgArgs a{};
+  sg_fill_args(a, pr, N);
+  a.mask = mask;
+  a.ch = SgChain{T, level_tab, flags, seed, graph_id0, x};
+  const size_t lds = SG_LDS_FLOATS * sizeof(float);
+  auto kern = split ? sg_forward_kernel<false, true, true> : sg_forward_kernel<false, false, true>;
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "sg_chain_simple"));
+  hipLaunchKernelGGL(kern, dim3(B), dim3(SG_THREADS), lds, st, a, SgSave{});
+  return check_launch("sg_chain_simple");
 }
 
 // test hook: every workgroup fills all of its CU's allocatable LDS with `pattern` (tests/test_gpu_smallgraph.py poisons the

@@ -227,11 +227,33 @@ def _sigma_rows(levels, like):
     return rows
 
 
+_LEVEL_TABLES = {}
+
+
+def level_table_simple(levels, device):
+    """[T, 3] float32 on the device for ops.chain_simple: per level the network's noise input float32(sigma) (model._prepare's
+    rounding) and the keep / flip probabilities float32(1 - sigma), float32(sigma) (dppm_edgeflip_fwd's roundings from double).
+    Uploaded once per (schedule, device)."""
+    key = (tuple(levels), str(device))
+    tab = _LEVEL_TABLES.get(key)
+    if tab is None:
+        if len(_LEVEL_TABLES) > 64:
+            _LEVEL_TABLES.clear()
+        s = np.asarray(levels, dtype=np.float64)
+        host = np.stack([s.astype(np.float32), (1.0 - s).astype(np.float32), s.astype(np.float32)], 1)
+        tab = _LEVEL_TABLES[key] = torch.as_tensor(np.ascontiguousarray(host), device=device)
+    return tab
+
+
 @torch.no_grad()
 def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None):
     """x_T ~ Bern(1/2), then for sigma descending: re-noise x0_hat to sigma, predict flips, sample, XOR
-    (sample_ppgn_simple.py:70-88).  flags [B,N] float32 on the GPU.  Returns the final adjacency [B,N,N]."""
+    (sample_ppgn_simple.py:70-88).  flags [B,N] float32 on the GPU.  Returns the final adjacency [B,N,N].
+    Small networks (hidden 32, N <= 20) run the whole chain as ONE launch -- same draws, same arithmetic, same bits as the
+    level-by-level loop below, which stays for every other network and whenever `record` wants the intermediate tensors."""
     mask = ops.generate_mask(flags)
+    if record is None and getattr(model, "chain_simple_supported", None) is not None and model.chain_simple_supported(flags.shape[1]):
+        return model.chain_simple(flags, mask, level_table_simple(schedule_simple(noise_num), flags.device), seed, graph_id0)
     x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
     a_t = torch.empty_like(x)
     logits = torch.empty_like(x)

@@ -157,3 +157,52 @@ def test_fused_forward_ignores_stale_lds(ops, N):
         got, _ = run_gpu(ops, W, A, mask, sigma, 3, 32)
         assert np.isfinite(got).all()
         close(got, want, tol=5e-5)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("N,L,T", [(20, 6, 16), (13, 3, 7), (5, 2, 4), (1, 1, 3), (16, 4, 5)])
+def test_chain_simple_in_one_launch_is_the_level_by_level_chain(N, L, T, precision):
+    """dppm_ppgn_chain_simple (x_T, then T x re-noise / denoise / reverse step inside one kernel) against the same chain run
+    through dppm_init_xT, dppm_edgeflip_fwd, dppm_ppgn_forward and dppm_reverse_step_simple: the same Philox counters and the same
+    float expressions, so the sampled adjacency is compared for EQUALITY; ragged graphs (inactive nodes) included, and the LDS is
+    poisoned with NaN patterns first (the adjacency and logits planes of the chain live there)."""
+    import ctypes as C
+    from discrete_dppm_graphs_amd import engine
+    from discrete_dppm_graphs_amd._lib import check, lib
+    from discrete_dppm_graphs_amd.model.ppgn import Powerful
+    torch.manual_seed(100 + N)
+    model = Powerful(num_layers=L, hidden=32, hidden_final=32, n_nodes=N, normalization="instance", adj_out=True, input_features=2,
+                     dropout_p=1e-6, config={"precision": precision}).cuda().eval()
+    assert model.precision == precision
+    B = 37
+    rng = np.random.default_rng(N)
+    flags = np.zeros((B, N), np.float32)
+    for b in range(B):
+        flags[b, :rng.integers(1, N + 1)] = 1.0
+    flags = torch.from_numpy(flags).cuda()
+    assert model.chain_simple_supported(N)
+    check(lib.dppm_test_fill_lds(0x7FC00000, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dppm_test_fill_lds")
+    one = engine.sample_chain_simple(model, flags, T, seed=9, graph_id0=5)
+    steps = []
+    ref = engine.sample_chain_simple(model, flags, T, seed=9, graph_id0=5, record=lambda c, a_t, logits, x: steps.append(c))
+    assert steps == list(range(T))                     # the recording form went level by level
+    assert torch.equal(one, ref)
+    assert torch.equal(one, one.transpose(1, 2)) and float(one.diagonal(dim1=1, dim2=2).abs().sum()) == 0.0
+    act = flags[:, :, None] * flags[:, None, :]
+    assert float((one * (1 - act)).abs().sum()) == 0.0   # nothing outside the active block
+    if N >= 13:
+        assert 0 < float(one.sum()) < float(act.sum())
+
+
+def test_chain_simple_entry_point_refuses_what_it_cannot_run():
+    from discrete_dppm_graphs_amd import engine, ops
+    from discrete_dppm_graphs_amd.model.ppgn import Powerful
+    model = Powerful(num_layers=2, hidden=32, hidden_final=32, n_nodes=24, normalization="instance", adj_out=True, input_features=2,
+                     dropout_p=1e-6).cuda().eval()
+    flags = torch.ones(3, 24, device="cuda")
+    assert not model.chain_simple_supported(24)
+    tab = engine.level_table_simple(engine.schedule_simple(4), flags.device)
+    with pytest.raises(RuntimeError, match="level by level"):
+        ops.chain_simple(model._pack(), flags, ops.generate_mask(flags), tab, seed=1)
+    x = engine.sample_chain_simple(model, flags, 4, seed=1)     # the engine falls back by itself
+    assert x.shape == (3, 24, 24)
