@@ -58,9 +58,11 @@ SIGNATURES = {
                                     C.c_size_t, C.c_int, C.c_int, c_stream]),
     "dppm_ppgn_backward": (C.c_int, [C.POINTER(PpgnParams), C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                      c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
-    "dppm_ppgn_chain_simple_supported": (C.c_int, [C.POINTER(PpgnParams), C.c_int]),
+    "dppm_ppgn_chain_supported": (C.c_int, [C.POINTER(PpgnParams), C.c_int]),
     "dppm_ppgn_chain_simple": (C.c_int, [C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                          c_f32p, C.c_int, c_stream]),
+    "dppm_ppgn_chain_vlb": (C.c_int, [C.POINTER(PpgnParams), c_f32p, c_f32p, c_f32p, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                      c_f32p, C.c_int, c_stream]),
     "dppm_plane_matmul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
                                     C.c_int, C.c_int, c_stream]),
     "dppm_linear_fwd": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_long, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_long,

@@ -1782,22 +1782,31 @@ extern "C" int dppm_ppgn_forward(const dppm_ppgn_params* pr, const float* A, con
   return check_launch("final_fwd");
 }
 
-// The whole simple sampling chain of small graphs in one launch (dppm_smallgraph.hip, CHAIN): see include/dppm_hip.h
-extern "C" int dppm_ppgn_chain_simple_supported(const dppm_ppgn_params* pr, int N) {
+// The whole sampling chain of small graphs in one launch (dppm_smallgraph.hip, CHAIN): see include/dppm_hip.h
+extern "C" int dppm_ppgn_chain_supported(const dppm_ppgn_params* pr, int N) {
   return pr && pr->hidden > 0 && sg_supported(pr, N) && sw(SW_DISABLE_SGCHAIN) == 0 ? 1 : 0;
+}
+static int chain_entry(bool vlb, const char* name, const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_table,
+                       int T, uint64_t seed, uint32_t graph_id0, int B, int N, float* x_out, int precision, void* stream) {
+  DPPM_TRY(check_params(pr, name));
+  DPPM_REQUIRE(valid_prec(precision), "%s: precision=%d", name, precision);
+  DPPM_REQUIRE(flags && mask && level_table && x_out, "%s: null pointer", name);
+  DPPM_REQUIRE(B > 0 && N > 0 && T > 0, "%s: B=%d N=%d T=%d must be positive", name, B, N, T);
+  DPPM_REQUIRE(sg_supported(pr, N), "%s: needs hidden 32, N <= %d, at most %d layers, no layer_cond (hidden=%d N=%d): "
+               "run the chain level by level (dppm_ppgn_forward and the dppm_reverse_step_* entry points)", name, SG_MAX_NODES, SG_MAX_LAYERS, pr->hidden, N);
+  const int prec = precision == DPPM_PREC_F32X6 ? DPPM_PREC_F32 : precision;
+  return sg_chain(vlb, pr, flags, mask, level_table, T, seed, graph_id0, B, N, x_out, as_stream(stream),
+                  prec == DPPM_PREC_BF16X3 && sw(SW_DISABLE_MLP32S) == 0);
 }
 extern "C" int dppm_ppgn_chain_simple(const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_table,
                                       int T, uint64_t seed, uint32_t graph_id0, int B, int N, float* x_out, int precision,
                                       void* stream) {
-  DPPM_TRY(check_params(pr, "dppm_ppgn_chain_simple"));
-  DPPM_REQUIRE(valid_prec(precision), "dppm_ppgn_chain_simple: precision=%d", precision);
-  DPPM_REQUIRE(flags && mask && level_table && x_out, "dppm_ppgn_chain_simple: null pointer");
-  DPPM_REQUIRE(B > 0 && N > 0 && T > 0, "dppm_ppgn_chain_simple: B=%d N=%d T=%d must be positive", B, N, T);
-  DPPM_REQUIRE(sg_supported(pr, N), "dppm_ppgn_chain_simple: needs hidden 32, N <= %d, at most %d layers, no layer_cond (hidden=%d N=%d): "
-               "run the chain level by level (dppm_edgeflip_fwd, dppm_ppgn_forward, dppm_reverse_step_simple)", SG_MAX_NODES, SG_MAX_LAYERS, pr->hidden, N);
-  const int prec = precision == DPPM_PREC_F32X6 ? DPPM_PREC_F32 : precision;
-  return sg_chain_simple(pr, flags, mask, level_table, T, seed, graph_id0, B, N, x_out, as_stream(stream),
-                         prec == DPPM_PREC_BF16X3 && sw(SW_DISABLE_MLP32S) == 0);
+  return chain_entry(false, "dppm_ppgn_chain_simple", pr, flags, mask, level_table, T, seed, graph_id0, B, N, x_out, precision, stream);
+}
+extern "C" int dppm_ppgn_chain_vlb(const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_table,
+                                   int T, uint64_t seed, uint32_t graph_id0, int B, int N, float* x_out, int precision,
+                                   void* stream) {
+  return chain_entry(true, "dppm_ppgn_chain_vlb", pr, flags, mask, level_table, T, seed, graph_id0, B, N, x_out, precision, stream);
 }
 
 extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_params* gr, const float* A, const float* mask,

@@ -20,9 +20,10 @@ bool sg_supported(const dppm_ppgn_params* pr, int N);
 int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, const float* sigma, int B, int N, float* logits,
                const SgSave* save, hipStream_t st, bool split = false);
 
-// The simple sampling chain, all T levels in one launch (x_T, re-noise, forward, reverse step per level; bit-identical to the
-// per-level kernels of dppm_diffusion.hip around sg_forward).  level_tab: [T][3] floats on the device, see include/dppm_hip.h.
-int sg_chain_simple(const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_tab, int T, uint64_t seed,
-                    uint32_t graph_id0, int B, int N, float* x, hipStream_t st, bool split);
+// A sampling chain, all T levels in one launch (x_T, then per level: simple = re-noise, forward, reverse step; vlb = forward,
+// posterior reverse step; bit-identical to the per-level kernels of dppm_diffusion.hip around sg_forward).  level_tab: [T][3]
+// (simple) or [T][7] (vlb) floats on the device, see include/dppm_hip.h.
+int sg_chain(bool vlb, const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_tab, int T, uint64_t seed,
+             uint32_t graph_id0, int B, int N, float* x, hipStream_t st, bool split);
 
 }  // namespace dppm

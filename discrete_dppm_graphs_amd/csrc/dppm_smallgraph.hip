@@ -53,13 +53,17 @@ __device__ unsigned long long sg_stamps[64];
 #define SG_T(i) do {} while (0)
 #endif
 
-// The simple sampling chain inside the kernel (CHAIN; sample_ppgn_simple.py:70-88): per level c the re-noising of x0_hat
-// (FlipOp of dppm_diffusion.hip, draw offset 1 + 2 c), the forward, the reverse step (RevSimpleOp, offset 2 + 2 c); x_T is InitOp's
-// (offset 0).  Thread tid < P owns entry (tid / ld, tid % ld) of the upper triangle and its mirror: the same Philox counters, the
-// same float expressions, hence the same bits as the per-level launches.
+// The sampling chains inside the kernel.  CHAIN == SG_SIMPLE (sample_ppgn_simple.py:70-88): per level c the re-noising of x0_hat
+// (FlipOp of dppm_diffusion.hip, draw offset 1 + 2 c), the forward, the reverse step (RevSimpleOp, offset 2 + 2 c).  CHAIN == SG_VLB
+// (sample_ppgn_vlb.py:111-131): the forward on A_t, then RevVlbOp (posterior mix, offset 1 + c).  x_T is InitOp's (offset 0).
+// Thread tid < P owns entry (tid / ld, tid % ld) of the upper triangle and its mirror: the same Philox counters, the same float
+// expressions (FP contraction off around them, as in dppm_diffusion.hip), hence the same bits as the per-level launches.
+constexpr int SG_NOCHAIN = 0, SG_SIMPLE = 1, SG_VLB = 2;
+constexpr int SG_TABW_SIMPLE = 3, SG_TABW_VLB = 7;
 struct SgChain {
   int T;                 // noise levels
-  const float* tab;      // [T][3] on the device: the network's noise input float(sigma), float(1 - sigma), float(sigma) (rounded from double)
+  const float* tab;      // device table, one row per level: the network's noise input, then SIMPLE: float(1 - sigma), float(sigma);
+                         // VLB: VlbConsts of dppm_diffusion.hip (1 - beta, beta, st1, 1 - st1, st, 1 - st), all rounded from double
   const float* flags;    // [B][N]
   uint64_t seed; uint32_t graph_id0;
   float* x;              // [B][N][N]: the sampled adjacency
@@ -328,7 +332,20 @@ __device__ __forceinline__ void sg_block_totals(floatx4 (&s)[2], float* __restri
 
 __device__ __forceinline__ float sg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }   // sigmoidf_dev of dppm_diffusion.hip
 
-template <int NTL, bool TWO, bool SAVE, bool SPLIT, bool CHAIN>
+// p(A_{t-1} = 1 | A_t) for one entry: posterior_mix of dppm_diffusion.hip (sample_ppgn_vlb.py:89-101), c = the level's six constants
+__device__ __forceinline__ float sg_posterior_mix(float a_t, float r_sym, const float* __restrict__ c) {
+#pragma clang fp contract(off)
+  const bool on = a_t > 0.5f;
+  const float s = on ? 1.f - r_sym : r_sym;
+  const float mult1 = on ? c[0] : c[1];
+  const float div0 = on ? c[4] : c[5];
+  float p = (1.f - s) * mult1 * c[2] / div0;
+  const float div1 = on ? c[5] : c[4];
+  p = p + s * mult1 * c[3] / div1;
+  return p;
+}
+
+template <int NTL, bool TWO, bool SAVE, bool SPLIT, int CHAINM>
 __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float* __restrict__ sg_lds) {
   float* O1 = sg_lds;
   float* O2 = O1 + 32 * SG_PITCH;
@@ -343,6 +360,8 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, q = lane >> 4, n = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile ownership tests become scalar branches
+  constexpr bool CHAIN = CHAINM != SG_NOCHAIN;
+  constexpr int TABW = CHAINM == SG_VLB ? SG_TABW_VLB : SG_TABW_SIMPLE;
   const int N = a.N, ld = a.ld, P = a.P, L = a.L;
   // The layer table is indexed at run time: read it where it lies, in the kernel-argument segment (SgArgs is the kernel's first
   // parameter, offset 0).  Through the by-value copy `a` a run-time index can make the compiler move the whole block to scratch.
@@ -408,7 +427,8 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   const float* ctab = a.ch.tab;                        // (locals: a lambda that names `a` would move the whole argument block to scratch)
   const uint64_t cseed = a.ch.seed;
   const uint32_t cgid = cg;
-  auto renoise = [=, &cx, &cfi, &cfj](int c) {   // (by value: nothing here may name `a`)   // FlipOp: keep an edge state with 1 - sigma, flip it with sigma
+  auto renoise = [=, &cx, &cfi, &cfj](int c) {   // FlipOp: keep an edge state with 1 - sigma, flip it with sigma  (captures by value: nothing here may name `a`)
+#pragma clang fp contract(off)
     const float pr = cx > 0.5f ? ctab[3 * c + 1] : ctab[3 * c + 2];
     const float v = philox_uniform(cseed, cgid, 1u + 2u * (uint32_t)c, (uint32_t)ci, (uint32_t)cj) < pr ? 1.f : 0.f;
     at[ci * ld + cj] = at[cj * ld + ci] = v * cfi * cfj;
@@ -420,7 +440,8 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       cfi = a.ch.flags[b * N + ci]; cfj = a.ch.flags[b * N + cj];
       const float pr = (cfi > 0.5f && cfj > 0.5f) ? 0.5f : 0.f;   // InitOp
       cx = philox_uniform(cseed, cg, 0u, (uint32_t)ci, (uint32_t)cj) < pr ? 1.f : 0.f;
-      renoise(0);
+      if (CHAINM == SG_SIMPLE) renoise(0);
+      else at[ci * ld + cj] = at[cj * ld + ci] = cx;   // VLB: the network sees A_t itself
     }
     __syncthreads();
   }
@@ -429,7 +450,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   for (int c = 0; c < nlev; ++c) {
   // input planes [A, sigma I], in_lin (model/ppgn.py:283-301) and the [A, sigma I] columns of layer_cat_lin (:318,327)
   floatx4 u[SG_TPW][2], yacc[SG_TPW][2];
-  const float sg = CHAIN ? ctab[3 * c] : a.sigma[b];
+  const float sg = CHAIN ? ctab[TABW * c] : a.sigma[b];
 #pragma unroll
   for (int ti = 0; ti < SG_TPW; ++ti) {
     const int pos = 16 * SG_TILE(ti) + n;
@@ -803,7 +824,8 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   if (CHAIN) {
     __syncthreads();                                   // the logits are complete and every wave is done with after_conv's weights
     sg_commit_a<SPLIT>(pf, W, tid);                    // layer 0's MLP weights for the next level (fetched behind the last commit above)
-    if (cup) {
+    if (cup && CHAINM == SG_SIMPLE) {
+#pragma clang fp contract(off)
       // RevSimpleOp: flip where the symmetrised probability says so, then (FlipOp) re-noise for the next level
       float r = (sg_sigmoid(lg[ci * ld + cj]) + sg_sigmoid(lg[cj * ld + ci])) / 2.f;
       r = r * ((cfi >= 0.9f && cfj >= 0.9f) ? 1.f : 0.f);
@@ -812,6 +834,18 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       const float inter = v > 0.5f ? av - 1.f : av;
       cx = inter < -0.5f ? inter + 2.f : inter;
       if (c + 1 < nlev) renoise(c + 1);
+    }
+    if (cup && CHAINM == SG_VLB) {
+#pragma clang fp contract(off)
+      // RevVlbOp: both orientations of the entry through the posterior mix, symmetrised, sampled
+      const float* vc = ctab + TABW * c + 1;
+      const float r_ij = sg_sigmoid(lg[ci * ld + cj]), r_ji = sg_sigmoid(lg[cj * ld + ci]);
+      const float r_up = (r_ij + r_ji) / 2.f, r_lo = (r_ji + r_ij) / 2.f;
+      const float p_ij = sg_posterior_mix(at[ci * ld + cj], r_up, vc), p_ji = sg_posterior_mix(at[cj * ld + ci], r_lo, vc);
+      float qq = (p_ij + p_ji) / 2.f;
+      qq = qq * ((cfi >= 0.9f && cfj >= 0.9f) ? 1.f : 0.f);
+      cx = philox_uniform(cseed, cg, 1u + (uint32_t)c, (uint32_t)ci, (uint32_t)cj) < qq ? 1.f : 0.f;
+      at[ci * ld + cj] = at[cj * ld + ci] = cx;
     }
     __syncthreads();
   }
@@ -822,7 +856,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
   }
 }
 
-template <bool SAVE, bool SPLIT, bool CHAIN>
+template <bool SAVE, bool SPLIT, int CHAIN>
 __global__ __launch_bounds__(SG_THREADS) void sg_forward_kernel(const SgArgs a, const SgSave sv) {
   extern __shared__ __attribute__((aligned(16))) float sg_lds[];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -859,23 +893,24 @@ int sg_forward(const dppm_ppgn_params* pr, const float* A, const float* mask, co
   a.A = A; a.mask = mask; a.sigma = sigma; a.logits = logits;
   const SgSave sv = save ? *save : SgSave{};
   const size_t lds = SG_LDS_FLOATS * sizeof(float);
-  auto kern = save ? sg_forward_kernel<true, false, false> : (split ? sg_forward_kernel<false, true, false> : sg_forward_kernel<false, false, false>);
+  auto kern = save ? sg_forward_kernel<true, false, SG_NOCHAIN> : (split ? sg_forward_kernel<false, true, SG_NOCHAIN> : sg_forward_kernel<false, false, SG_NOCHAIN>);
   DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "sg_forward"));
   hipLaunchKernelGGL(kern, dim3(B), dim3(SG_THREADS), lds, st, a, sv);
   return check_launch("sg_forward");
 }
 
-int sg_chain_simple(const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_tab, int T, uint64_t seed,
-                    uint32_t graph_id0, int B, int N, float* x, hipStream_t st, bool split) {
+int sg_chain(bool vlb, const dppm_ppgn_params* pr, const float* flags, const float* mask, const float* level_tab, int T, uint64_t seed,
+             uint32_t graph_id0, int B, int N, float* x, hipStream_t st, bool split) {
   SgArgs a{};
   sg_fill_args(a, pr, N);
   a.mask = mask;
   a.ch = SgChain{T, level_tab, flags, seed, graph_id0, x};
   const size_t lds = SG_LDS_FLOATS * sizeof(float);
-  auto kern = split ? sg_forward_kernel<false, true, true> : sg_forward_kernel<false, false, true>;
-  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "sg_chain_simple"));
+  auto kern = vlb ? (split ? sg_forward_kernel<false, true, SG_VLB> : sg_forward_kernel<false, false, SG_VLB>)
+                  : (split ? sg_forward_kernel<false, true, SG_SIMPLE> : sg_forward_kernel<false, false, SG_SIMPLE>);
+  DPPM_TRY(lds_limit(reinterpret_cast<const void*>(kern), lds, "sg_chain"));
   hipLaunchKernelGGL(kern, dim3(B), dim3(SG_THREADS), lds, st, a, SgSave{});
-  return check_launch("sg_chain_simple");
+  return check_launch("sg_chain");
 }
 
 // test hook: every workgroup fills all of its CU's allocatable LDS with `pattern` (tests/test_gpu_smallgraph.py poisons the

@@ -245,6 +245,24 @@ def level_table_simple(levels, device):
     return tab
 
 
+def level_table_vlb(sched, device):
+    """[T, 7] float32 on the device for ops.chain_vlb: per level float32(sigmatilde_t) for the network, then the six constants
+    dppm_reverse_step_vlb rounds from (sigmatilde_t, beta_t, sigmatilde_{t-1}): 1 - b, b, st1, 1 - st1, st, 1 - st."""
+    key = ("vlb", tuple(sched), str(device))
+    tab = _LEVEL_TABLES.get(key)
+    if tab is None:
+        if len(_LEVEL_TABLES) > 64:
+            _LEVEL_TABLES.clear()
+        st, bt, st1 = (np.asarray([row[k] for row in sched], dtype=np.float64) for k in range(3))
+        host = np.stack([st, 1.0 - bt, bt, st1, 1.0 - st1, st, 1.0 - st], 1).astype(np.float32)
+        tab = _LEVEL_TABLES[key] = torch.as_tensor(np.ascontiguousarray(host), device=device)
+    return tab
+
+
+def _one_launch(model, flags, record):
+    return record is None and getattr(model, "chain_supported", None) is not None and model.chain_supported(flags.shape[1])
+
+
 @torch.no_grad()
 def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None):
     """x_T ~ Bern(1/2), then for sigma descending: re-noise x0_hat to sigma, predict flips, sample, XOR
@@ -252,7 +270,7 @@ def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None)
     Small networks (hidden 32, N <= 20) run the whole chain as ONE launch -- same draws, same arithmetic, same bits as the
     level-by-level loop below, which stays for every other network and whenever `record` wants the intermediate tensors."""
     mask = ops.generate_mask(flags)
-    if record is None and getattr(model, "chain_simple_supported", None) is not None and model.chain_simple_supported(flags.shape[1]):
+    if _one_launch(model, flags, record):
         return model.chain_simple(flags, mask, level_table_simple(schedule_simple(noise_num), flags.device), seed, graph_id0)
     x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
     a_t = torch.empty_like(x)
@@ -270,8 +288,11 @@ def sample_chain_simple(model, flags, noise_num, seed, graph_id0=0, record=None)
 
 @torch.no_grad()
 def sample_chain_vlb(model, flags, noise_num, seed, graph_id0=0, record=None):
-    """x_T ~ Bern(1/2), then t = T..1: predict flips, mix posteriors, sample A_{t-1} (sample_ppgn_vlb.py:111-131)."""
+    """x_T ~ Bern(1/2), then t = T..1: predict flips, mix posteriors, sample A_{t-1} (sample_ppgn_vlb.py:111-131).
+    Small networks: one launch for the whole chain, as in sample_chain_simple."""
     mask = ops.generate_mask(flags)
+    if _one_launch(model, flags, record):
+        return model.chain_vlb(flags, mask, level_table_vlb(schedule_vlb(noise_num), flags.device), seed, graph_id0)
     x = ops.init_xT(flags, seed=seed, graph_id0=graph_id0, offset=0)
     y = torch.empty_like(x)
     logits = torch.empty_like(x)

@@ -237,14 +237,18 @@ class Powerful(nn.Module):
         return ops.ppgn_forward(self._pack(), A, mask, sigma, self._workspace(B, N, False, A.device), training=False, out=out,
                                 precision=self.precision)
 
-    def chain_simple_supported(self, N):
-        """The whole simple sampling chain as one launch (include/dppm_hip.h dppm_ppgn_chain_simple): small networks only, and not
-        with a learned noise embedding (time_mlp is torch code in front of the kernels)."""
-        return not self.noise_mlp and ops.chain_simple_supported(self._pack(), N)
+    def chain_supported(self, N):
+        """A whole sampling chain as one launch (include/dppm_hip.h dppm_ppgn_chain_*): small networks only, and not with a
+        learned noise embedding (time_mlp is torch code in front of the kernels)."""
+        return not self.noise_mlp and ops.chain_supported(self._pack(), N)
 
     @torch.no_grad()
     def chain_simple(self, flags, mask, level_table, seed, graph_id0=0, out=None):
         return ops.chain_simple(self._pack(), flags, mask, level_table, seed, graph_id0, out=out, precision=self.precision)
+
+    @torch.no_grad()
+    def chain_vlb(self, flags, mask, level_table, seed, graph_id0=0, out=None):
+        return ops.chain_vlb(self._pack(), flags, mask, level_table, seed, graph_id0, out=out, precision=self.precision)
 
     # ------------------------------------------------------------------ helpers
     def used_param_names(self):

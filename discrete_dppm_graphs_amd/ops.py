@@ -248,26 +248,35 @@ def ppgn_forward(pack, A, mask, sigma, workspace, training=False, out=None, prec
     return logits
 
 
-def chain_simple_supported(pack, N):
-    """Whether the whole simple chain of this network at N nodes runs as one launch (hidden 32, N <= 20: include/dppm_hip.h)."""
-    return bool(lib.dppm_ppgn_chain_simple_supported(pack.ref(), int(N)))
+def chain_supported(pack, N):
+    """Whether a whole sampling chain of this network at N nodes runs as one launch (hidden 32, N <= 20: include/dppm_hip.h)."""
+    return bool(lib.dppm_ppgn_chain_supported(pack.ref(), int(N)))
+
+
+def _chain(fn, name, width, pack, flags, mask, level_table, seed, graph_id0, out, precision):
+    flags = _chk(flags, "flags")
+    B, N = flags.shape
+    mask = _chk(mask, "mask", (B, N, N))
+    level_table = _chk(level_table, "level_table")
+    if level_table.dim() != 2 or level_table.shape[1] != width:
+        raise ValueError(f"level_table must be [T, {width}], got {tuple(level_table.shape)}")
+    x = out if out is not None else torch.empty(B, N, N, device=flags.device, dtype=torch.float32)
+    _chk(x, "out", (B, N, N))
+    check(fn(pack.ref(), _ptr(flags), _ptr(mask), _ptr(level_table), int(level_table.shape[0]), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+             C.c_uint32(int(graph_id0)), B, N, _ptr(x), _prec(precision), _stream()), name)
+    return x
 
 
 def chain_simple(pack, flags, mask, level_table, seed, graph_id0=0, out=None, precision="f32"):
     """x_T, then T x (re-noise, denoise, reverse step) in one launch; level_table [T, 3] float32 on the device
     (engine.level_table_simple).  Bit-identical to init_xT / edgeflip / ppgn_forward / reverse_step_simple level by level."""
-    flags = _chk(flags, "flags")
-    B, N = flags.shape
-    mask = _chk(mask, "mask", (B, N, N))
-    level_table = _chk(level_table, "level_table")
-    if level_table.dim() != 2 or level_table.shape[1] != 3:
-        raise ValueError(f"level_table must be [T, 3], got {tuple(level_table.shape)}")
-    x = out if out is not None else torch.empty(B, N, N, device=flags.device, dtype=torch.float32)
-    _chk(x, "out", (B, N, N))
-    check(lib.dppm_ppgn_chain_simple(pack.ref(), _ptr(flags), _ptr(mask), _ptr(level_table), int(level_table.shape[0]),
-                                     C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(graph_id0)), B, N, _ptr(x), _prec(precision), _stream()),
-          "dppm_ppgn_chain_simple")
-    return x
+    return _chain(lib.dppm_ppgn_chain_simple, "dppm_ppgn_chain_simple", 3, pack, flags, mask, level_table, seed, graph_id0, out, precision)
+
+
+def chain_vlb(pack, flags, mask, level_table, seed, graph_id0=0, out=None, precision="f32"):
+    """x_T, then T x (denoise, posterior reverse step) in one launch; level_table [T, 7] float32 on the device
+    (engine.level_table_vlb).  Bit-identical to init_xT / ppgn_forward / reverse_step_vlb level by level."""
+    return _chain(lib.dppm_ppgn_chain_vlb, "dppm_ppgn_chain_vlb", 7, pack, flags, mask, level_table, seed, graph_id0, out, precision)
 
 
 def ppgn_backward(pack, grad_pack, A, mask, sigma, dlogits, workspace, dsigma=None):

@@ -193,19 +193,25 @@ int dppm_ppgn_backward(const dppm_ppgn_params* params_host, const dppm_ppgn_para
                        const float* A, const float* mask, const float* sigma, int B, int N,
                        const float* dlogits, float* dsigma, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The whole "simple" sampling chain of small graphs in ONE launch: x_T (dppm_init_xT, draw offset 0), then for level c = 0 .. T-1
- * the re-noising of the running estimate (dppm_edgeflip_fwd, offset 1 + 2 c), the denoiser (dppm_ppgn_forward, inference) and the
- * reverse step (dppm_reverse_step_simple, offset 2 + 2 c) -- one workgroup per graph, adjacency, activations and logits stay in
- * registers and LDS, only x_out [B][N][N] is written.  Same Philox counters and float expressions as those entry points: x_out is
- * bit-identical to calling them level by level at the same precision.
- *   level_table: T x 3 floats ON THE DEVICE, row c = { (float)sigma_c : the network's noise input,
- *                (float)(1.0 - sigma_c), (float)sigma_c : the keep / flip probabilities, rounded from double as dppm_edgeflip_fwd does }.
- * Only where dppm_ppgn_chain_simple_supported() returns 1 (hidden 32, N <= 20, <= 16 layers, no layer_cond: the reference's
- * community_small / ego_small networks); otherwise DPPM_E_INVALID, and the chain is run through the per-level entry points.
- * Replaces the loop of sample_ppgn_simple.py:70-88 (48 launches for 16 levels) for those networks. */
-int dppm_ppgn_chain_simple_supported(const dppm_ppgn_params* params_host, int N);
+/* A whole sampling chain of small graphs in ONE launch -- one workgroup per graph; adjacency, activations and logits stay in
+ * registers and LDS, only x_out [B][N][N] is written.  Same Philox counters and float expressions as the per-level entry points:
+ * x_out is bit-identical to calling them level by level at the same precision.
+ *   dppm_ppgn_chain_simple: x_T (dppm_init_xT, draw offset 0), then for level c = 0 .. T-1 the re-noising of the running estimate
+ *     (dppm_edgeflip_fwd, offset 1 + 2 c), the denoiser (dppm_ppgn_forward, inference), the reverse step (dppm_reverse_step_simple,
+ *     offset 2 + 2 c).  level_table: T x 3 floats ON THE DEVICE, row c = { (float)sigma_c : the network's noise input,
+ *     (float)(1.0 - sigma_c), (float)sigma_c : keep / flip probabilities, rounded from double as dppm_edgeflip_fwd does }.
+ *     Replaces the loop of sample_ppgn_simple.py:70-88 (48 launches for 16 levels).
+ *   dppm_ppgn_chain_vlb: x_T, then per level the denoiser on A_t and dppm_reverse_step_vlb (offset 1 + c).  level_table: T x 7
+ *     floats on the device, row c = { (float)sigmatilde_t, then (float) of 1 - beta_t, beta_t, sigmatilde_{t-1}, 1 - sigmatilde_{t-1},
+ *     sigmatilde_t, 1 - sigmatilde_t : the constants dppm_reverse_step_vlb rounds from its three doubles }.
+ *     Replaces the loop of sample_ppgn_vlb.py:111-131.
+ * Only where dppm_ppgn_chain_supported() returns 1 (hidden 32, N <= 20, <= 16 layers, no layer_cond: the reference's
+ * community_small / ego_small networks); otherwise DPPM_E_INVALID, and the chain is run through the per-level entry points. */
+int dppm_ppgn_chain_supported(const dppm_ppgn_params* params_host, int N);
 int dppm_ppgn_chain_simple(const dppm_ppgn_params* params_host, const float* flags, const float* mask, const float* level_table,
                            int T, uint64_t seed, uint32_t graph_id0, int B, int N, float* x_out, int precision, void* stream);
+int dppm_ppgn_chain_vlb(const dppm_ppgn_params* params_host, const float* flags, const float* mask, const float* level_table,
+                        int T, uint64_t seed, uint32_t graph_id0, int B, int N, float* x_out, int precision, void* stream);
 
 /* Building blocks, exported for tests and for callers that schedule layers themselves. */
 

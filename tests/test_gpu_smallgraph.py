@@ -159,12 +159,13 @@ def test_fused_forward_ignores_stale_lds(ops, N):
         close(got, want, tol=5e-5)
 
 
+@pytest.mark.parametrize("kind", ["simple", "vlb"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("N,L,T", [(20, 6, 16), (13, 3, 7), (5, 2, 4), (1, 1, 3), (16, 4, 5)])
-def test_chain_simple_in_one_launch_is_the_level_by_level_chain(N, L, T, precision):
-    """dppm_ppgn_chain_simple (x_T, then T x re-noise / denoise / reverse step inside one kernel) against the same chain run
-    through dppm_init_xT, dppm_edgeflip_fwd, dppm_ppgn_forward and dppm_reverse_step_simple: the same Philox counters and the same
-    float expressions, so the sampled adjacency is compared for EQUALITY; ragged graphs (inactive nodes) included, and the LDS is
+def test_chain_in_one_launch_is_the_level_by_level_chain(N, L, T, precision, kind):
+    """dppm_ppgn_chain_simple / _vlb (x_T, then every level inside one kernel) against the same chain run through dppm_init_xT,
+    dppm_edgeflip_fwd, dppm_ppgn_forward and dppm_reverse_step_simple / _vlb: the same Philox counters and the same float
+    expressions, so the sampled adjacency is compared for EQUALITY; ragged graphs (inactive nodes) included, and the LDS is
     poisoned with NaN patterns first (the adjacency and logits planes of the chain live there)."""
     import ctypes as C
     from discrete_dppm_graphs_amd import engine
@@ -180,29 +181,34 @@ def test_chain_simple_in_one_launch_is_the_level_by_level_chain(N, L, T, precisi
     for b in range(B):
         flags[b, :rng.integers(1, N + 1)] = 1.0
     flags = torch.from_numpy(flags).cuda()
-    assert model.chain_simple_supported(N)
+    assert model.chain_supported(N)
+    chain = engine.sample_chain_simple if kind == "simple" else engine.sample_chain_vlb
     check(lib.dppm_test_fill_lds(0x7FC00000, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dppm_test_fill_lds")
-    one = engine.sample_chain_simple(model, flags, T, seed=9, graph_id0=5)
+    one = chain(model, flags, T, seed=9, graph_id0=5)
     steps = []
-    ref = engine.sample_chain_simple(model, flags, T, seed=9, graph_id0=5, record=lambda c, a_t, logits, x: steps.append(c))
+    ref = chain(model, flags, T, seed=9, graph_id0=5, record=lambda c, a_t, logits, x: steps.append(c))
     assert steps == list(range(T))                     # the recording form went level by level
     assert torch.equal(one, ref)
     assert torch.equal(one, one.transpose(1, 2)) and float(one.diagonal(dim1=1, dim2=2).abs().sum()) == 0.0
     act = flags[:, :, None] * flags[:, None, :]
     assert float((one * (1 - act)).abs().sum()) == 0.0   # nothing outside the active block
-    if N >= 13:
+    if N >= 13 and kind == "simple":
         assert 0 < float(one.sum()) < float(act.sum())
 
 
-def test_chain_simple_entry_point_refuses_what_it_cannot_run():
+def test_chain_entry_points_refuse_what_they_cannot_run():
     from discrete_dppm_graphs_amd import engine, ops
     from discrete_dppm_graphs_amd.model.ppgn import Powerful
     model = Powerful(num_layers=2, hidden=32, hidden_final=32, n_nodes=24, normalization="instance", adj_out=True, input_features=2,
                      dropout_p=1e-6).cuda().eval()
     flags = torch.ones(3, 24, device="cuda")
-    assert not model.chain_simple_supported(24)
+    assert not model.chain_supported(24)
     tab = engine.level_table_simple(engine.schedule_simple(4), flags.device)
     with pytest.raises(RuntimeError, match="level by level"):
         ops.chain_simple(model._pack(), flags, ops.generate_mask(flags), tab, seed=1)
-    x = engine.sample_chain_simple(model, flags, 4, seed=1)     # the engine falls back by itself
-    assert x.shape == (3, 24, 24)
+    with pytest.raises(RuntimeError, match="level by level"):
+        ops.chain_vlb(model._pack(), flags, ops.generate_mask(flags), engine.level_table_vlb(engine.schedule_vlb(4), flags.device), seed=1)
+    with pytest.raises(ValueError, match="level_table"):
+        ops.chain_vlb(model._pack(), flags, ops.generate_mask(flags), tab, seed=1)
+    for chain in (engine.sample_chain_simple, engine.sample_chain_vlb):     # the engine falls back by itself
+        assert chain(model, flags, 4, seed=1).shape == (3, 24, 24)
