@@ -36,7 +36,7 @@ struct Layout {
   size_t rstd;                     // [L][B][H]
   size_t himg;                     // inference, H = 128: bf16 weight fragments of the fused read-out head (dppm_head.h)
   size_t nstat, ncnt, naff;        // inference, H = 128 / 32: per-tile statistics [B*tpp][H][2], counts [B*tpp], (scale, shift) tables [L+1][B][2][H]
-  size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to four 32 x 32 weight gradients (H = 32)
+  size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to six 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
 };
@@ -93,7 +93,7 @@ Layout make_layout(int B, int N, int H, int L, int training) {
     if (H == WS_H && w.slab_floats < ws_wgrad_scratch_floats()) w.slab_floats = ws_wgrad_scratch_floats();
     w.slabs = bump(off, w.slab_floats);
     w.rsum = bump(off, (size_t)nz * H + (size_t)B * H + B);
-    w.w32 = H == 32 ? bump(off, (size_t)4 * nz * (1024 + 32)) : 0;
+    w.w32 = H == 32 ? bump(off, (size_t)6 * nz * (1024 + 32)) : 0;   // 6 = W32_MAXJOBS
   }
   w.total = off;
   return w;
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
   wgrad32_body(dY, dy_bs, X, x_bs, P, nsplit, kchunk, slabs, rsum, blockIdx.x);
 }
 
-// Up to four independent 32 x 32 weight gradients in one launch (a layer's m4 halves and second MLP matrices, or its two first MLP
-// matrices), and their slab reductions in one more: the per-matrix pairs of launches were 47 % of a small-network training step.
-constexpr int W32_MAXJOBS = 4;
+// Up to six independent 32 x 32 weight gradients in one launch (ALL of a layer's: m4's halves, both MLPs' matrices), and their slab
+// reductions in one more: the per-matrix pairs of launches were 47 % of a small-network training step.
+constexpr int W32_MAXJOBS = 6;
 struct W32Job { const float* dY; long dy_bs; const float* X; long x_bs; float* dW; int ldo; float* db; };
 struct W32Args { W32Job job[W32_MAXJOBS]; int njobs, P, nsplit, kchunk, nz; float* slabs; float* rsum; };   // slabs [job][nz][1024], rsum [job][nz][32]
 __global__ __launch_bounds__(256) void wgrad32m_kernel(const W32Args a) {
@@ -1933,23 +1933,24 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     float* gw1[2] = {gq.m1_w1, gq.m2_w1}; float* gb1[2] = {gq.m1_b1, gq.m2_b1};
     const bool m32_off = sw(SW_DISABLE_LIN32) != 0;
     if (!ws && H == 32 && !m32_off) {   // small networks: both MLP backward chains in one launch (dpre_1 -> dy, dpre_2 -> dmm, both free here)
-      if (multi) {   // dy is still m4's output gradient here: four weight gradients in one launch, before dy is reused for dpre_1
-        const W32Job jobs[4] = {{dy, hs, mm, hs, gq.m4_w, 2 * H, gq.m4_b}, {dy, hs, x, x_bs, gq.m4_w + H, 2 * H, nullptr},
-                                {dout[0], hs, hid[0], hs, gw1[0], H, gb1[0]}, {dout[1], hs, hid[1], hs, gw1[1], H, gb1[1]}};
-        DPPM_TRY(wgrad32_multi(c, jobs, 4));
-      } else {
+      // multi: dpre_1 goes to dz instead (the head's after_conv gradient: scratch of this call, free since the head's backward), so
+      // that dy is still m4's output gradient afterwards and ALL six weight gradients of the layer ride one launch behind the MLP chains
+      float* dpre1 = multi ? dz : dy;
+      if (!multi) {
         DPPM_TRY(wgrad(c, H, dout[0], hs, H, hid[0], hs, gw1[0], H, gb1[0]));
         DPPM_TRY(wgrad(c, H, dout[1], hs, H, hid[1], hs, gw1[1], H, gb1[1]));
       }
       const bool prof = prof_enabled();
       if (prof) prof_before(c.st);
       hipLaunchKernelGGL(mlp32_bwd_kernel, dim3(cdiv((long)B * cdiv(P, 16), 4)), dim3(256), 0, c.st, do1, do2, hid1, hid2, hs, wl1[0], wl1[1], wl0[0],
-                         wl0[1], dy, dmm, dx, dx_bs, P, B);
+                         wl0[1], dpre1, dmm, dx, dx_bs, P, B);
       if (prof) prof_after(c.st, PROF_LINEAR, AR_F32, 8.0 * 32 * 32 * (double)P * B);
       DPPM_TRY(check_launch("mlp32_bwd"));
       if (multi) {
-        const W32Job jobs[2] = {{dy, hs, x, x_bs, gw0[0], H, gb0[0]}, {dmm, hs, x, x_bs, gw0[1], H, gb0[1]}};
-        DPPM_TRY(wgrad32_multi(c, jobs, 2));
+        const W32Job jobs[6] = {{dy, hs, mm, hs, gq.m4_w, 2 * H, gq.m4_b}, {dy, hs, x, x_bs, gq.m4_w + H, 2 * H, nullptr},
+                                {dout[0], hs, hid[0], hs, gw1[0], H, gb1[0]}, {dout[1], hs, hid[1], hs, gw1[1], H, gb1[1]},
+                                {dpre1, hs, x, x_bs, gw0[0], H, gb0[0]}, {dmm, hs, x, x_bs, gw0[1], H, gb0[1]}};
+        DPPM_TRY(wgrad32_multi(c, jobs, 6));
       } else {
         DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gw0[0], H, gb0[0]));
         DPPM_TRY(wgrad(c, H, dmm, hs, H, x, x_bs, gw0[1], H, gb0[1]));
