@@ -120,13 +120,11 @@ __device__ __forceinline__ void plane_store_tile(const floatx4& acc, float* __re
 constexpr int plane_waves_per_simd(int nt) { return (!DPPM_PLANE_FORCE_OCC || nt >= 14) ? (nt + 3) / 4 : ((32 / nt) * nt + 3) / 4; }
 
 template <int NT, bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(NT * 64, plane_waves_per_simd(NT)) void plane_mm_kernel(const PlaneArgs p) {
+__device__ __forceinline__ void plane_mm_body(const PlaneArgs& p, const int g, float* __restrict__ lds) {
   using Cfg = PlaneCfg<NT>;
   constexpr int NVPT = 1;   // blockDim.x == 64 * NT threads move the NT*16 x 16 panel as one float4 each
-  __shared__ __attribute__((aligned(16))) float lds[4 * Cfg::PANEL];   // [stage][A,B]
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = blockIdx.x;
   const size_t plane = (size_t)p.n * p.ld;
   const float* A = p.A + g * plane;
   const float* B = p.B + g * plane;
@@ -172,6 +170,28 @@ __global__ __launch_bounds__(NT * 64, plane_waves_per_simd(NT)) void plane_mm_ke
   float* C = p.C + g * plane;
 #pragma unroll
   for (int j = 0; j < NT; ++j) plane_store_tile(acc[j], C, mask, scale, wave * 16, j * 16, n, ld, lane);
+}
+template <int NT, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(NT * 64, plane_waves_per_simd(NT)) void plane_mm_kernel(const PlaneArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * PlaneCfg<NT>::PANEL];   // [stage][A,B]
+  plane_mm_body<NT, A_KMAJOR, B_KMAJOR>(p, blockIdx.x, lds);
+}
+// The two products of the contraction's backward in ONE launch (small networks, where a launch costs more than its work):
+// workgroups [0, batch) form p1 = A * B^T (do1 = dmm o2^T), workgroups [batch, 2 batch) form p2 = A^T * B (do2 = o1^T dmm).
+template <int NT>
+__global__ __launch_bounds__(NT * 64, plane_waves_per_simd(NT)) void plane_mm_pair_kernel(const PlaneArgs p1, const PlaneArgs p2, int batch) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * PlaneCfg<NT>::PANEL];
+  if ((int)blockIdx.x < batch) plane_mm_body<NT, false, false>(p1, blockIdx.x, lds);   // (block-uniform)
+  else plane_mm_body<NT, true, true>(p2, blockIdx.x - batch, lds);
+}
+inline bool plane_mm_pair_ok(int n) { return n <= 32; }
+inline int plane_mm_pair_launch(const PlaneArgs& p1, const PlaneArgs& p2, int batch, hipStream_t st) {
+  const bool prof = prof_enabled();
+  if (prof) prof_before(st);
+  if (p1.n <= 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(plane_mm_pair_kernel<1>), dim3(2 * batch), dim3(64), 0, st, p1, p2, batch);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(plane_mm_pair_kernel<2>), dim3(2 * batch), dim3(128), 0, st, p1, p2, batch);
+  if (prof) prof_after(st, PROF_PLANE_MM, AR_F32, 4.0 * p1.n * p1.n * (double)p1.n * batch, 6.0 * sizeof(float) * p1.n * (double)p1.ld * batch);
+  return check_launch("plane_mm_pair");
 }
 
 template <int NT>

@@ -1923,8 +1923,14 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       DPPM_TRY(linear(c, H, LinArgs{q.m4_w + H, 2 * H, true, dy, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dx, dx_bs, l != 0));
     }
     // contraction: do1 = dmm o2^T / sqrt(n) * mask ; do2 = o1^T dmm / sqrt(n) * mask
+    if (!ws && H == 32 && plane_mm_pair_ok(N) && sw(SW_DISABLE_LIN32) == 0 && aligned16(dmm) && aligned16(o1) && aligned16(o2) && aligned16(do1) &&
+        aligned16(do2)) {   // small networks: both products in one launch (exact-f32 MFMAs, the arithmetic the two calls below use at this size)
+      const PlaneArgs p1{dmm, o2, do1, N, w.ld, c.at(w.inv_norm), maskp, H}, p2{o1, dmm, do2, N, w.ld, c.at(w.inv_norm), maskp, H};
+      DPPM_TRY(plane_mm_pair_launch(p1, p2, B * H, c.st));
+    } else {
     DPPM_TRY(plane_mm(c.st, dmm, o2, do1, B * H, N, w.ld, false, true, c.at(w.inv_norm), maskp, H, DPPM_PREC_F32X6));
     DPPM_TRY(plane_mm(c.st, o1, dmm, do2, B * H, N, w.ld, true, false, c.at(w.inv_norm), maskp, H, DPPM_PREC_F32X6));
+    }
     // m1 (dy is free again: reuse it for the pre-activation gradient)
     float* dpre = dy;
     const float* dout[2] = {do1, do2}; const float* hid[2] = {hid1, hid2};
