@@ -36,12 +36,14 @@ struct Layout {
   size_t rstd;                     // [L][B][H]
   size_t himg;                     // inference, H = 128: bf16 weight fragments of the fused read-out head (dppm_head.h)
   size_t nstat, ncnt, naff;        // inference, H = 128 / 32: per-tile statistics [B*tpp][H][2], counts [B*tpp], (scale, shift) tables [L+1][B][2][H]
+  int w32_layers;
   size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to six 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
 };
 
 constexpr size_t kAlign = 64;   // floats (256 B)
+constexpr int W32_DEFER_MAXL = 16, W32_DEFER_MAXNZ = 64;   // small networks: per-layer weight-gradient slabs, folded by one launch (wgrad32_multi)
 inline size_t bump(size_t& off, size_t n) {
   const size_t at = off;
   off += (n + kAlign - 1) / kAlign * kAlign;
@@ -93,7 +95,9 @@ Layout make_layout(int B, int N, int H, int L, int training) {
     if (H == WS_H && w.slab_floats < ws_wgrad_scratch_floats()) w.slab_floats = ws_wgrad_scratch_floats();
     w.slabs = bump(off, w.slab_floats);
     w.rsum = bump(off, (size_t)nz * H + (size_t)B * H + B);
-    w.w32 = H == 32 ? bump(off, (size_t)6 * nz * (1024 + 32)) : 0;   // 6 = W32_MAXJOBS
+    // 6 = W32_MAXJOBS; few slabs (small graphs) and few layers: every layer keeps its own set, ONE reduction launch folds them all
+    w.w32_layers = (H == 32 && nz <= W32_DEFER_MAXNZ && L <= W32_DEFER_MAXL) ? L : 1;
+    w.w32 = H == 32 ? bump(off, (size_t)6 * w.w32_layers * nz * (1024 + 32)) : 0;
   }
   w.total = off;
   return w;
@@ -515,11 +519,16 @@ __global__ __launch_bounds__(256) void wgrad32m_kernel(const W32Args a) {
   const W32Job& q = a.job[j];
   wgrad32_body(q.dY, q.dy_bs, q.X, q.x_bs, a.P, a.nsplit, a.kchunk, a.slabs + (size_t)j * a.nz * 1024, a.rsum + (size_t)j * a.nz * 32, z);
 }
+// The fold of the slabs, for the jobs of one launch above or (small graphs: W32_DEFER_*) for those of ALL layers of a backward pass at once:
+// job j's slabs at slabs + j * nz * 1024, its row sums at rsum + j * nz * 32
+constexpr int R32_MAXJOBS = W32_MAXJOBS * W32_DEFER_MAXL;
+struct R32Out { float* dW; int ldo; float* db; };
+struct R32Args { R32Out job[R32_MAXJOBS]; int njobs, nz; const float* slabs; const float* rsum; };
 // per job: 32 blocks fold dW (32 outputs each), one block folds db; fixed order as reduce_slabs_kernel
-__global__ __launch_bounds__(RS_E * RS_G) void reduce32m_kernel(const W32Args a) {
+__global__ __launch_bounds__(RS_E * RS_G) void reduce32m_kernel(const R32Args a) {
   __shared__ float part[RS_G][RS_E];
   const int j = blockIdx.x / 33, kind = blockIdx.x - j * 33;
-  const W32Job& q = a.job[j];
+  const R32Out q = a.job[j];
   const bool bias = kind == 32;                                    // block-uniform
   const int g = threadIdx.x / RS_E, t = threadIdx.x % RS_E;
   const float* src = bias ? a.rsum + (size_t)j * a.nz * 32 : a.slabs + (size_t)j * a.nz * 1024;
@@ -1450,10 +1459,23 @@ bool wgrad32_multi_ok(const Ctx& c) {
   const bool off = sw(SW_DISABLE_WGRAD32) != 0;
   return !off && c.w.H == 32 && c.w.training && c.w.P % 4 == 0 && wgrad_kchunk(c.w.B, c.w.P) <= W32_MAXK;
 }
-int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
+// `pend` != nullptr (a backward pass over a small network, W32_DEFER_*): the launch writes into its own set of slabs and the fold is
+// left to wgrad32_flush, one launch for every layer's jobs; otherwise the fold follows at once.
+struct W32Pending { R32Args r; int sets; };
+int wgrad32_flush(const Ctx& c, W32Pending& pd) {
+  if (pd.r.njobs == 0) return DPPM_OK;
+  hipLaunchKernelGGL(reduce32m_kernel, dim3(pd.r.njobs * 33), dim3(RS_E * RS_G), 0, c.st, pd.r);
+  pd.r.njobs = 0; pd.sets = 0;
+  return check_launch("reduce32m");
+}
+int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs, W32Pending* pend = nullptr) {
   W32Args a{};
   a.njobs = njobs; a.P = c.w.P; a.nsplit = wgrad_nsplit(c.w.B, c.w.P); a.kchunk = wgrad_kchunk(c.w.B, c.w.P); a.nz = c.w.B * a.nsplit;
-  a.slabs = c.at(c.w.w32); a.rsum = a.slabs + (size_t)W32_MAXJOBS * a.nz * 1024;
+  const bool defer = pend && c.w.w32_layers > 1 && pend->sets < c.w.w32_layers && pend->r.njobs + njobs <= R32_MAXJOBS;
+  float* slabs0 = c.at(c.w.w32);
+  float* rsum0 = slabs0 + (size_t)W32_MAXJOBS * c.w.w32_layers * a.nz * 1024;
+  const int jbase = defer ? pend->r.njobs : 0;   // (deferred sets are packed by job: set s starts where set s - 1 ended)
+  a.slabs = slabs0 + (size_t)jbase * a.nz * 1024; a.rsum = rsum0 + (size_t)jbase * a.nz * 32;
   for (int j = 0; j < njobs; ++j) {
     a.job[j] = jobs[j];
     DPPM_REQUIRE(aligned16(jobs[j].dY) && aligned16(jobs[j].X) && jobs[j].dy_bs % 4 == 0 && jobs[j].x_bs % 4 == 0, "wgrad32_multi: unaligned operand");
@@ -1465,7 +1487,17 @@ int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs) {
   hipLaunchKernelGGL(wgrad32m_kernel, dim3(njobs * a.nz), dim3(256), lds, c.st, a);
   if (prof) prof_after(c.st, PROF_WGRAD, AR_F32, 2.0 * 32 * 32 * (double)c.w.P * c.w.B * njobs);
   DPPM_TRY(check_launch("wgrad32m"));
-  hipLaunchKernelGGL(reduce32m_kernel, dim3(njobs * 33), dim3(RS_E * RS_G), 0, c.st, a);
+  if (defer) {
+    pend->r.nz = a.nz; pend->r.slabs = slabs0; pend->r.rsum = rsum0;
+    for (int j = 0; j < njobs; ++j) pend->r.job[pend->r.njobs++] = R32Out{jobs[j].dW, jobs[j].ldo, jobs[j].db};
+    ++pend->sets;
+    return DPPM_OK;
+  }
+  if (pend) DPPM_TRY(wgrad32_flush(c, *pend));   // (out of sets: fold what is pending before the shared region would be reused)
+  R32Args r{};
+  r.njobs = njobs; r.nz = a.nz; r.slabs = a.slabs; r.rsum = a.rsum;
+  for (int j = 0; j < njobs; ++j) r.job[j] = R32Out{jobs[j].dW, jobs[j].ldo, jobs[j].db};
+  hipLaunchKernelGGL(reduce32m_kernel, dim3(njobs * 33), dim3(RS_E * RS_G), 0, c.st, r);
   return check_launch("reduce32m");
 }
 
@@ -1881,6 +1913,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     DPPM_TRY(linear(c, w.CT, LinArgs{pr->cat_w, w.CT, true, dh, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dcat, cat_bs, false));
   }
 
+  W32Pending w32_pending{};   // small networks: the layers' weight-gradient slabs are folded by one launch after the loop
   for (int l = L - 1; l >= 0; --l) {
     const dppm_ppgn_layer& q = pr->layers_host[l];
     const dppm_ppgn_layer& gq = gr->layers_host[l];
@@ -1956,7 +1989,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
         const W32Job jobs[6] = {{dy, hs, mm, hs, gq.m4_w, 2 * H, gq.m4_b}, {dy, hs, x, x_bs, gq.m4_w + H, 2 * H, nullptr},
                                 {dout[0], hs, hid[0], hs, gw1[0], H, gb1[0]}, {dout[1], hs, hid[1], hs, gw1[1], H, gb1[1]},
                                 {dpre1, hs, x, x_bs, gw0[0], H, gb0[0]}, {dmm, hs, x, x_bs, gw0[1], H, gb0[1]}};
-        DPPM_TRY(wgrad32_multi(c, jobs, 6));
+        DPPM_TRY(wgrad32_multi(c, jobs, 6, &w32_pending));
       } else {
         DPPM_TRY(wgrad(c, H, dy, hs, H, x, x_bs, gw0[0], H, gb0[0]));
         DPPM_TRY(wgrad(c, H, dmm, hs, H, x, x_bs, gw0[1], H, gb0[1]));
@@ -1992,6 +2025,7 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       DPPM_TRY(check_launch("diag_sum"));
     }
   }
+  DPPM_TRY(wgrad32_flush(c, w32_pending));
   // in_lin
   DPPM_TRY(wgrad(c, H, du0, hs, 2, cat, cat_bs, gr->in_w, 2, gr->in_b));
   if (dsigma) {   // dh still holds dR (nothing after the head reuses it)
