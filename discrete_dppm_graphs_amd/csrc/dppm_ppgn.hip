@@ -36,7 +36,7 @@ struct Layout {
   size_t rstd;                     // [L][B][H]
   size_t himg;                     // inference, H = 128: bf16 weight fragments of the fused read-out head (dppm_head.h)
   size_t nstat, ncnt, naff;        // inference, H = 128 / 32: per-tile statistics [B*tpp][H][2], counts [B*tpp], (scale, shift) tables [L+1][B][2][H]
-  int w32_layers;
+  int w32_jobs;
   size_t dh, dz, dcat, dy, dmm, do1, do2, du0, slabs, rsum, w32;   // w32: slabs + row sums of up to six 32 x 32 weight gradients (H = 32)
   size_t slab_floats, total;
   int training;
@@ -95,9 +95,10 @@ Layout make_layout(int B, int N, int H, int L, int training) {
     if (H == WS_H && w.slab_floats < ws_wgrad_scratch_floats()) w.slab_floats = ws_wgrad_scratch_floats();
     w.slabs = bump(off, w.slab_floats);
     w.rsum = bump(off, (size_t)nz * H + (size_t)B * H + B);
-    // 6 = W32_MAXJOBS; few slabs (small graphs) and few layers: every layer keeps its own set, ONE reduction launch folds them all
-    w.w32_layers = (H == 32 && nz <= W32_DEFER_MAXNZ && L <= W32_DEFER_MAXL) ? L : 1;
-    w.w32 = H == 32 ? bump(off, (size_t)6 * w.w32_layers * nz * (1024 + 32)) : 0;
+    // few slabs (small graphs) and few layers: every weight-gradient launch keeps its own slabs, ONE reduction launch folds them all
+    // (8 = W32_MAXJOBS; deferred: six jobs per layer, the head's L + 2 and in_lin's one)
+    w.w32_jobs = (H == 32 && nz <= W32_DEFER_MAXNZ && L <= W32_DEFER_MAXL) ? 7 * L + 3 : 8;
+    w.w32 = H == 32 ? bump(off, (size_t)w.w32_jobs * nz * (1024 + 32)) : 0;
   }
   w.total = off;
   return w;
@@ -511,8 +512,8 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
 
 // Up to six independent 32 x 32 weight gradients in one launch (ALL of a layer's: m4's halves, both MLPs' matrices), and their slab
 // reductions in one more: the per-matrix pairs of launches were 47 % of a small-network training step.
-constexpr int W32_MAXJOBS = 6;
-struct W32Job { const float* dY; long dy_bs; const float* X; long x_bs; float* dW; int ldo; float* db; };
+constexpr int W32_MAXJOBS = 8;
+struct W32Job { const float* dY; long dy_bs; const float* X; long x_bs; float* dW; int ldo; float* db; int ncols; };   // ncols: columns of the 32 x 32 block that are stored (0 = all 32)
 struct W32Args { W32Job job[W32_MAXJOBS]; int njobs, P, nsplit, kchunk, nz; float* slabs; float* rsum; };   // slabs [job][nz][1024], rsum [job][nz][32]
 __global__ __launch_bounds__(256) void wgrad32m_kernel(const W32Args a) {
   const int j = blockIdx.x / a.nz, z = blockIdx.x - j * a.nz;
@@ -521,8 +522,8 @@ __global__ __launch_bounds__(256) void wgrad32m_kernel(const W32Args a) {
 }
 // The fold of the slabs, for the jobs of one launch above or (small graphs: W32_DEFER_*) for those of ALL layers of a backward pass at once:
 // job j's slabs at slabs + j * nz * 1024, its row sums at rsum + j * nz * 32
-constexpr int R32_MAXJOBS = W32_MAXJOBS * W32_DEFER_MAXL;
-struct R32Out { float* dW; int ldo; float* db; };
+constexpr int R32_MAXJOBS = 7 * W32_DEFER_MAXL + 3;
+struct R32Out { float* dW; int ldo; float* db; int ncols; };
 struct R32Args { R32Out job[R32_MAXJOBS]; int njobs, nz; const float* slabs; const float* rsum; };
 // per job: 32 blocks fold dW (32 outputs each), one block folds db; fixed order as reduce_slabs_kernel
 __global__ __launch_bounds__(RS_E * RS_G) void reduce32m_kernel(const R32Args a) {
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(RS_E * RS_G) void reduce32m_kernel(const R32Args a)
 #pragma unroll
     for (int k = 1; k < RS_G; ++k) v += part[k][t];
     if (bias) { if (q.db) q.db[e] = v; }
-    else q.dW[(size_t)(e >> 5) * q.ldo + (e & 31)] = v;
+    else if ((e & 31) < (q.ncols ? q.ncols : 32)) q.dW[(size_t)(e >> 5) * q.ldo + (e & 31)] = v;
   }
 }
 
@@ -1461,19 +1462,20 @@ bool wgrad32_multi_ok(const Ctx& c) {
 }
 // `pend` != nullptr (a backward pass over a small network, W32_DEFER_*): the launch writes into its own set of slabs and the fold is
 // left to wgrad32_flush, one launch for every layer's jobs; otherwise the fold follows at once.
-struct W32Pending { R32Args r; int sets; };
+struct W32Pending { R32Args r; };
 int wgrad32_flush(const Ctx& c, W32Pending& pd) {
   if (pd.r.njobs == 0) return DPPM_OK;
   hipLaunchKernelGGL(reduce32m_kernel, dim3(pd.r.njobs * 33), dim3(RS_E * RS_G), 0, c.st, pd.r);
-  pd.r.njobs = 0; pd.sets = 0;
+  pd.r.njobs = 0;
   return check_launch("reduce32m");
 }
 int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs, W32Pending* pend = nullptr) {
   W32Args a{};
   a.njobs = njobs; a.P = c.w.P; a.nsplit = wgrad_nsplit(c.w.B, c.w.P); a.kchunk = wgrad_kchunk(c.w.B, c.w.P); a.nz = c.w.B * a.nsplit;
-  const bool defer = pend && c.w.w32_layers > 1 && pend->sets < c.w.w32_layers && pend->r.njobs + njobs <= R32_MAXJOBS;
+  DPPM_REQUIRE(njobs >= 1 && njobs <= W32_MAXJOBS, "wgrad32_multi: %d jobs", njobs);
+  const bool defer = pend && c.w.w32_jobs > W32_MAXJOBS && pend->r.njobs + njobs <= c.w.w32_jobs && pend->r.njobs + njobs <= R32_MAXJOBS;
   float* slabs0 = c.at(c.w.w32);
-  float* rsum0 = slabs0 + (size_t)W32_MAXJOBS * c.w.w32_layers * a.nz * 1024;
+  float* rsum0 = slabs0 + (size_t)c.w.w32_jobs * a.nz * 1024;
   const int jbase = defer ? pend->r.njobs : 0;   // (deferred sets are packed by job: set s starts where set s - 1 ended)
   a.slabs = slabs0 + (size_t)jbase * a.nz * 1024; a.rsum = rsum0 + (size_t)jbase * a.nz * 32;
   for (int j = 0; j < njobs; ++j) {
@@ -1489,14 +1491,13 @@ int wgrad32_multi(const Ctx& c, const W32Job* jobs, int njobs, W32Pending* pend 
   DPPM_TRY(check_launch("wgrad32m"));
   if (defer) {
     pend->r.nz = a.nz; pend->r.slabs = slabs0; pend->r.rsum = rsum0;
-    for (int j = 0; j < njobs; ++j) pend->r.job[pend->r.njobs++] = R32Out{jobs[j].dW, jobs[j].ldo, jobs[j].db};
-    ++pend->sets;
+    for (int j = 0; j < njobs; ++j) pend->r.job[pend->r.njobs++] = R32Out{jobs[j].dW, jobs[j].ldo, jobs[j].db, jobs[j].ncols};
     return DPPM_OK;
   }
   if (pend) DPPM_TRY(wgrad32_flush(c, *pend));   // (out of sets: fold what is pending before the shared region would be reused)
   R32Args r{};
   r.njobs = njobs; r.nz = a.nz; r.slabs = a.slabs; r.rsum = a.rsum;
-  for (int j = 0; j < njobs; ++j) r.job[j] = R32Out{jobs[j].dW, jobs[j].ldo, jobs[j].db};
+  for (int j = 0; j < njobs; ++j) r.job[j] = R32Out{jobs[j].dW, jobs[j].ldo, jobs[j].db, jobs[j].ncols};
   hipLaunchKernelGGL(reduce32m_kernel, dim3(njobs * 33), dim3(RS_E * RS_G), 0, c.st, r);
   return check_launch("reduce32m");
 }
@@ -1878,9 +1879,13 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(H, RS_E) + 1), dim3(RS_E * RS_G), 0, c.st, (const float*)part, B, 1, H, gr->final_w, H,
                      (const float*)(part + (size_t)B * H), gr->final_b);
   DPPM_TRY(check_launch("reduce(dwfin, dbfin)"));
-  DPPM_TRY(wgrad(c, H, dz, hs, H, c.at(w.R), hs, gr->after_w, H, gr->after_b));
-  // dR = dh + W_ac^T dz   (accumulated into dh)
   const bool ws = use_wstat(H);
+  // small networks: the head's weight gradients (after_conv, layer_cat_lin block by block) as 32 x 32 jobs of ONE launch behind dR,
+  // in_lin's as one more at the end, every fold in the single launch after the layer loop (wgrad32_multi)
+  W32Pending w32_pending{};
+  const bool head32 = !ws && H == 32 && sw(SW_DISABLE_LIN32) == 0 && wgrad32_multi_ok(c) && L + 2 <= W32_MAXJOBS && aligned16(cat) && cat_bs % 4 == 0;
+  if (!head32) DPPM_TRY(wgrad(c, H, dz, hs, H, c.at(w.R), hs, gr->after_w, H, gr->after_b));
+  // dR = dh + W_ac^T dz   (accumulated into dh)
   if (ws) {
     WsArgs wa{};
     wa.njobs = 1; wa.B = B; wa.P = P;
@@ -1895,6 +1900,10 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     for (int j = 0; j < L; ++j)
       DPPM_TRY(wgrad(c, H, dh, hs, H, cat + (size_t)(2 + j * H) * P, cat_bs, gr->cat_w + 2 + (size_t)j * H, w.CT, j == 0 ? gr->cat_b : nullptr));
     DPPM_TRY(wgrad(c, H, dh, hs, 2, cat, cat_bs, gr->cat_w, w.CT, nullptr));
+  } else if (head32) {
+    W32Job jobs[W32_MAXJOBS] = {{dz, hs, c.at(w.R), hs, gr->after_w, H, gr->after_b, 0}, {dh, hs, cat, cat_bs, gr->cat_w, w.CT, gr->cat_b, 2}};
+    for (int j = 0; j < L; ++j) jobs[2 + j] = W32Job{dh, hs, cat + (size_t)(2 + j * H) * P, cat_bs, gr->cat_w + 2 + (size_t)j * H, w.CT, nullptr, 0};
+    DPPM_TRY(wgrad32_multi(c, jobs, L + 2, &w32_pending));
   } else {
     DPPM_TRY(wgrad(c, H, dh, hs, w.CT, cat, cat_bs, gr->cat_w, w.CT, gr->cat_b));
   }
@@ -1913,7 +1922,6 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
     DPPM_TRY(linear(c, w.CT, LinArgs{pr->cat_w, w.CT, true, dh, hs, H}, nullptr, nullptr, 0, nullptr, nullptr, 0, dcat, cat_bs, false));
   }
 
-  W32Pending w32_pending{};   // small networks: the layers' weight-gradient slabs are folded by one launch after the loop
   for (int l = L - 1; l >= 0; --l) {
     const dppm_ppgn_layer& q = pr->layers_host[l];
     const dppm_ppgn_layer& gq = gr->layers_host[l];
@@ -2025,9 +2033,13 @@ extern "C" int dppm_ppgn_backward(const dppm_ppgn_params* pr, const dppm_ppgn_pa
       DPPM_TRY(check_launch("diag_sum"));
     }
   }
-  DPPM_TRY(wgrad32_flush(c, w32_pending));
   // in_lin
-  DPPM_TRY(wgrad(c, H, du0, hs, 2, cat, cat_bs, gr->in_w, 2, gr->in_b));
+  if (head32) {
+    const W32Job job{du0, hs, cat, cat_bs, gr->in_w, 2, gr->in_b, 2};   // (the first 32 planes of CAT; only the two input columns are stored)
+    DPPM_TRY(wgrad32_multi(c, &job, 1, &w32_pending));
+  }
+  DPPM_TRY(wgrad32_flush(c, w32_pending));
+  if (!head32) DPPM_TRY(wgrad(c, H, du0, hs, 2, cat, cat_bs, gr->in_w, 2, gr->in_b));
   if (dsigma) {   // dh still holds dR (nothing after the head reuses it)
     hipLaunchKernelGGL(dsigma_kernel, dim3(B), dim3(256), 0, c.st, (const float*)du0, (const float*)dh, pr->in_w, pr->cat_w, w.CT, H, N, w.ld, dsigma);
     DPPM_TRY(check_launch("dsigma"));
