@@ -20,7 +20,7 @@ out = (ctypes.c_ulonglong * 64)()
 lib = L.lib
 lib.dppm_sg_read_stamps.restype = ctypes.c_int
 assert lib.dppm_sg_read_stamps(out) == 0
-names = ["mlp", "barrier", "contraction", "barrier", "m4", "totals1", "totals2", "norm+readout", "commit"]
+names = ["mlp", "barrier+weights", "contraction", "barrier", "m4", "totals1", "totals2", "norm+readout", "commit"]
 for w in range(2):
     t = [out[16 * w + i] for i in range(10)]
     print("wave", w, "layer cycles", t[9] - t[0], " ".join(f"{n}={t[i + 1] - t[i]}" for i, n in enumerate(names)))
