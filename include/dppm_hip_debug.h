@@ -27,7 +27,7 @@ int dppm_test_fill_lds(uint32_t pattern, void* stream);
 
 /* Experiment switches.  Each selects an older kernel for the same arithmetic (DISABLE_W4, W3MLP, DISABLE_NORMFUSE, DISABLE_HEAD3,
  * DISABLE_INLINFUSE, DISABLE_PLANE4, DISABLE_PLANE6, DISABLE_W6, DISABLE_W6MLP, DISABLE_MLP32, DISABLE_LIN32, DISABLE_WGRAD32,
- * DISABLE_STRIPMM, DISABLE_WIDE32, DISABLE_SMALLGRAPH, DISABLE_WSTAT, WGRAD_F32, PLANE_STRIPS_ONLY) or a timing experiment with WRONG results
+ * DISABLE_STRIPMM, DISABLE_WIDE32, DISABLE_MLP32S, DISABLE_SMALLGRAPH, DISABLE_SGCHAIN, DISABLE_WSTAT, WGRAD_F32, PLANE_STRIPS_ONLY) or a timing experiment with WRONG results
  * (DBG, DBG_P4, DBG_W4).  The library reads them once per process from the environment (DPPM_<NAME>; unset or 0 = off) into one
  * table; afterwards these two calls are the only way to change or read one.  Unknown names return DPPM_E_INVALID. */
 int dppm_debug_set(const char* name, int value);
