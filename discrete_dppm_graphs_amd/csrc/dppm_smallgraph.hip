@@ -49,8 +49,10 @@ constexpr int SG_LDS_FLOATS = 2 * 32 * SG_PITCH + SG_W_TOTAL + SG_MP + 2 * SG_NW
 #ifdef SG_STAMP
 __device__ unsigned long long sg_stamps[64];
 #define SG_T(i) do { if (l == 2 && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && w < 2) { __builtin_amdgcn_sched_barrier(0); sg_stamps[16 * w + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define SG_TK(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && w < 2) { __builtin_amdgcn_sched_barrier(0); sg_stamps[16 * w + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)   /* whole-kernel marks: slots 10 .. 13 */
 #else
 #define SG_T(i) do {} while (0)
+#define SG_TK(i) do {} while (0)
 #endif
 
 // The sampling chains inside the kernel.  CHAIN == SG_SIMPLE (sample_ppgn_simple.py:70-88): per level c the re-noising of x0_hat
@@ -370,6 +372,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
 #define SG_TILE(ti) (w + SG_NW * (ti))
 #define SG_HAS(ti) ((ti) < NTL)
 
+  SG_TK(10);
   float pf[SG_NPF];
   sg_fetch_a(pf, sg_ptr_a(ka, 0), tid);
   if (tid < SG_MP) {
@@ -478,6 +481,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     sg_store_tiles<NTL>(sv.u0 + gS, P, u, so);
   }
 
+  SG_TK(11);
   for (int l = 0; l < L; ++l) {
     const SgPtrB pB = sg_ptr_b(ka, l);
     const SgPtrA pA = sg_ptr_a(ka, l + 1);
@@ -795,6 +799,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     SG_T(9);
   }
 
+  SG_TK(12);
   // ---- head: out + LeakyReLU(after_conv(out)), final_lin (model/ppgn.py:331-333; dropout is the identity in eval)
   const float fb = a.final_b[0];
 #pragma unroll
@@ -821,6 +826,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
     const int i = pos / ld, j = pos - i * ld;
     if (q == 0 && pos < P && j < N) (CHAIN ? lg + pos : a.logits + ((size_t)b * N + i) * N + j)[0] = part + fb;
   }
+  SG_TK(13);
   if (CHAIN) {
     __syncthreads();                                   // the logits are complete and every wave is done with after_conv's weights
     sg_commit_a<SPLIT>(pf, W, tid);                    // layer 0's MLP weights for the next level (fetched behind the last commit above)

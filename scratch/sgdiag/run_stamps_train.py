@@ -24,4 +24,6 @@ assert L.lib.dppm_sg_read_stamps(out) == 0
 names = ["mlp", "barrier+weights", "contraction", "barrier", "m4", "totals1", "totals2", "norm+readout", "commit"]
 for w in range(2):
     t = [out[16 * w + i] for i in range(10)]
+    k = [out[16 * w + i] for i in range(10, 14)]
+    print("  whole kernel: setup", k[1] - k[0], "layers", k[2] - k[1], "head", k[3] - k[2])
     print("train" if train else "infer-f32", "wave", w, "layer cycles", t[9] - t[0], " ".join(f"{n}={t[i + 1] - t[i]}" for i, n in enumerate(names)))
