@@ -107,6 +107,26 @@ def test_schedules_match_oracle_and_fixture():
     assert sched.shape == (3, 3) and sched[0, 2] == 0.0 and sched[1, 0] == 0.5
 
 
+def test_level_tables_of_the_one_launch_chains_hold_the_per_level_roundings():
+    """engine.level_table_simple / level_table_vlb (what dppm_ppgn_chain_* read per level): the network's noise input is the float32
+    rounding model._prepare makes of the python double, the probabilities are formed in double and rounded once, as FlipOp /
+    make_vlb_consts of csrc/dppm_diffusion.hip do -- that is what makes the one-launch chain bit-identical to the per-level calls."""
+    from discrete_dppm_graphs_amd import engine
+    for T in (4, 16, 64):
+        s = engine.schedule_simple(T)
+        tab = engine.level_table_simple(s, "cpu").numpy()
+        assert tab.shape == (T, 3) and tab.dtype == np.float32
+        for c, sg in enumerate(s):
+            assert tab[c, 0] == np.float32(sg) and tab[c, 1] == np.float32(1.0 - sg) and tab[c, 2] == np.float32(sg)
+        v = engine.schedule_vlb(T)
+        tv = engine.level_table_vlb(v, "cpu").numpy()
+        assert tv.shape == (T, 7) and tv.dtype == np.float32
+        for c, (st, bt, st1) in enumerate(v):
+            want = [st, 1.0 - bt, bt, st1, 1.0 - st1, st, 1.0 - st]
+            assert tv[c].tolist() == [float(np.float32(x)) for x in want]
+    assert engine.level_table_simple(engine.schedule_simple(16), "cpu") is engine.level_table_simple(engine.schedule_simple(16), "cpu")   # cached
+
+
 def test_configs_parse_and_carry_reference_keys(tmp_path, monkeypatch):
     from discrete_dppm_graphs_amd.utils import arg_helper
     monkeypatch.chdir(tmp_path)
