@@ -842,7 +842,7 @@ __device__ __forceinline__ void a32_leaky(A32& a) {
 #pragma unroll
     for (int co = 0; co < 2; ++co)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float v = a.a[j][co][r]; a.a[j][co][r] = v > 0.f ? v : kSlope * v; }
+      for (int r = 0; r < 4; ++r) { const float v = a.a[j][co][r]; a.a[j][co][r] = fmaxf(v, kSlope * v); }   // slope < 1: the larger IS the activation (two instructions, not three)
 }
 // the source's folded instance norm: x * scale + shift per channel; a lane's eight (scale, shift) pairs of the graph's [2][32] table
 // (norm_finalize_kernel)
