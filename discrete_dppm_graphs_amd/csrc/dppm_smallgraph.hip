@@ -27,6 +27,13 @@ namespace {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr float kSlopeSg = 0.01f;   // LeakyReLU negative slope, model/ppgn.py:7
 
+// sg_opaque: the LDS addresses of a weight commit are a few shifts and adds of tid.  Hoisted out of the layer loop as loop
+// invariants they were SPILLED, and every commit then began with a chain of scratch reloads, each waited for with vmcnt(0): 2 k
+// cycles per layer.  Behind this empty asm tid is a fresh value at every commit: the addresses are formed there and die there.
+// (The same treatment for the weight-fragment, bias and reduction-slot addresses removes every spill from the layer loop and is
+// SLOWER, 32.3 k -> 30.5 k graphs/s: the kernel is bound by VALU issue, and re-forming addresses per use costs more than the reloads.)
+__device__ __forceinline__ int sg_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 constexpr int SG_PITCH = 404;       // floats between channel planes (== 4 mod 64)
 constexpr int SG_NW = 8;             // waves per workgroup (256 VGPRs each: u, the readout accumulators and the m4 result of four tiles stay in registers)
 constexpr int SG_TPW = 4;           // position tiles per wave: 25 tiles of 16 positions at N = 20
@@ -129,6 +136,7 @@ __device__ __forceinline__ void sg_wput2(float* __restrict__ W, int o0, int o1, 
 template <bool SPLIT>
 __device__ __forceinline__ void sg_commit_a(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
   static_assert(SG_SPM == 2, "two elements of every matrix per thread");
+  tid = sg_opaque(tid);
   {
     const int i0 = tid, i1 = tid + SG_THREADS;
     const int o0 = (i0 >> 5) * SG_WP + (i0 & 31), o1 = (i1 >> 5) * SG_WP + (i1 & 31);
@@ -153,6 +161,7 @@ __device__ __forceinline__ void sg_fetch_b(float (&pf)[SG_NPF], const SgPtrB& p,
 }
 template <bool SPLIT>
 __device__ __forceinline__ void sg_commit_b(const float (&pf)[SG_NPF], float* __restrict__ W, int tid) {
+  tid = sg_opaque(tid);
   {
     const int i0 = tid, i1 = tid + SG_THREADS;
     sg_wput2<SPLIT>(W + SG_W_CAT, (i0 >> 5) * SG_WP + (i0 & 31), (i1 >> 5) * SG_WP + (i1 & 31), pf[0], pf[1]);
@@ -569,13 +578,14 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
         // 16-byte LDS reads per fragment (o2 was stored transposed for this), the result one 16-byte write per tile -- 8 + 4 LDS
         // instructions and 12 MFMAs of 16 cycles per channel in place of 20 + 16 and 20 MFMAs of 32 cycles.  The operands arrive
         // already split (see the MLP phase's store): splitting them here, per fragment slot, cost more VALU time than all of that.
-        const int ia[2] = {min(n, N - 1), min(16 + n, N - 1)}, ja[2] = {min(n, ld - 1), min(16 + n, ld - 1)};
-        const int k0 = q < 3 ? 8 * q : 0;
+        const int qo = q, no = n;
+        const int ia[2] = {min(no, N - 1), min(16 + no, N - 1)}, ja[2] = {min(no, ld - 1), min(16 + no, ld - 1)};
+        const int k0 = qo < 3 ? 8 * qo : 0;
         // byte selectors of v_perm_b32 per pair of k (0x0c: a zero byte -- the slots of k >= N, whatever the words there hold)
         unsigned hs[4], ls[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool l0 = q < 3 && 8 * q + 2 * e < N, l1 = q < 3 && 8 * q + 2 * e + 1 < N;
+          const bool l0 = qo < 3 && 8 * qo + 2 * e < N, l1 = qo < 3 && 8 * qo + 2 * e + 1 < N;
           hs[e] = (l0 ? 0x0302u : 0x0c0cu) | (l1 ? 0x07060000u : 0x0c0c0000u);
           ls[e] = (l0 ? 0x0100u : 0x0c0cu) | (l1 ? 0x05040000u : 0x0c0c0000u);
         }
@@ -605,7 +615,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
             for (int y = 0; y < 2; ++y) {
               if ((x || y) && !two) continue;
               const floatx4 d = sg_mfma3(ah[y], al[y], bh[x], bl[x], floatx4{0.f, 0.f, 0.f, 0.f});
-              const int i = 16 * x + n, j = 16 * y + 4 * q;
+              const int i = 16 * x + no, j = 16 * y + 4 * qo;
               if (i < N && j < ld) *reinterpret_cast<float4*>(pa + i * ld + j) = make_float4(d[0], d[1], d[2], d[3]);   // (1 / sqrt(n): in o1 already)
             }
         }
@@ -725,6 +735,7 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
       // statistics in ONE exchange: every wave's own sum and its sum of squares about ITS OWN mean (both passes stay inside the
       // wave: registers and DPP row sums), then the pooled variance from the eight (count, mean, M2) -- as stable as two passes over
       // the block, one barrier less
+      const int q4s = 4 * q;
       {
         const float rcw = cwt[SG_NW + w];
 #pragma unroll
@@ -750,8 +761,8 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
             sw4[r] = sa; qw4[r] = sg_row_sum(qa);
           }
           if (n == 0) {
-            *reinterpret_cast<float4*>(red1 + w * 32 + 16 * co + 4 * q) = make_float4(sw4[0], sw4[1], sw4[2], sw4[3]);
-            *reinterpret_cast<float4*>(red2 + w * 32 + 16 * co + 4 * q) = make_float4(qw4[0], qw4[1], qw4[2], qw4[3]);
+            *reinterpret_cast<float4*>(red1 + w * 32 + 16 * co + q4s) = make_float4(sw4[0], sw4[1], sw4[2], sw4[3]);
+            *reinterpret_cast<float4*>(red2 + w * 32 + 16 * co + q4s) = make_float4(qw4[0], qw4[1], qw4[2], qw4[3]);
           }
         }
       }
@@ -764,15 +775,15 @@ __device__ __forceinline__ void sg_run(const SgArgs& a, const SgSave& sv, float*
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < SG_NW; ++k) {
-          const float4 v = *reinterpret_cast<const float4*>(red1 + k * 32 + 16 * co + 4 * q);
+          const float4 v = *reinterpret_cast<const float4*>(red1 + k * 32 + 16 * co + q4s);
           t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
         mean[co][0] = t.x * rcnt; mean[co][1] = t.y * rcnt; mean[co][2] = t.z * rcnt; mean[co][3] = t.w * rcnt;
         floatx4 m2 = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < SG_NW; ++k) {
-          const float4 v = *reinterpret_cast<const float4*>(red1 + k * 32 + 16 * co + 4 * q);
-          const float4 g = *reinterpret_cast<const float4*>(red2 + k * 32 + 16 * co + 4 * q);
+          const float4 v = *reinterpret_cast<const float4*>(red1 + k * 32 + 16 * co + q4s);
+          const float4 g = *reinterpret_cast<const float4*>(red2 + k * 32 + 16 * co + q4s);
           const float ck = cwt[k], rck = cwt[SG_NW + k];
           const float d0 = v.x * rck - mean[co][0], d1 = v.y * rck - mean[co][1], d2 = v.z * rck - mean[co][2], d3 = v.w * rck - mean[co][3];
           m2[0] += g.x + ck * d0 * d0; m2[1] += g.y + ck * d1 * d1; m2[2] += g.z + ck * d2 * d2; m2[3] += g.w + ck * d3 * d3;
