@@ -43,7 +43,7 @@ struct Layout {
 };
 
 constexpr size_t kAlign = 64;   // floats (256 B)
-constexpr int W32_DEFER_MAXL = 16, W32_DEFER_MAXNZ = 64;   // small networks: per-layer weight-gradient slabs, folded by one launch (wgrad32_multi)
+constexpr int W32_DEFER_MAXL = 16, W32_DEFER_MAXNZ = 512;   // small networks: per-layer weight-gradient slabs, folded by one launch (wgrad32_multi)
 inline size_t bump(size_t& off, size_t n) {
   const size_t at = off;
   off += (n + kAlign - 1) / kAlign * kAlign;
